@@ -1,0 +1,223 @@
+/*
+ * C ABI of the MI355X (gfx950) path-tracing library `librt_hip.so`.
+ *
+ * The reference (Mighty-A/RayTracer, Rust) has no FFI boundary: its hot path is
+ * the thread closure of src/main.rs:193-230, which calls Camera::get_ray
+ * (src/camera.rs:61-71) and ray_color (src/color.rs:34-63), which in turn calls
+ * Hittable::hit (src/hittable.rs:43-46), Material::scatter/emitted
+ * (src/material.rs:8-20) and Texture::value (src/texture.rs:8-10). The entry
+ * points below are what a `raytracer-hip-sys` crate would bind to replace that
+ * closure: the host keeps building scenes with the reference's constructors,
+ * flattens the Arc<dyn Hittable> tree into the tables of RtSceneDesc, and calls
+ * rt_render instead of looping over pixels.
+ *
+ * Conventions: plain pointers and sizes; inputs are borrowed for the duration of
+ * the call; outputs are caller-allocated; RtScene is library-owned and immutable.
+ * Every function returns 0 on success and a negative RT_E* code otherwise (the
+ * reference panics instead: src/bvh.rs:86,124, src/vec3.rs:285-286); nothing
+ * unwinds or aborts across the boundary. rt_last_error() returns a thread-local
+ * message for the last failure on the calling thread. A scene lives on the HIP
+ * device that was current when it was created; calls on one scene are
+ * serialised by the caller, calls on different scenes may run concurrently.
+ *
+ * All arithmetic is IEEE binary64 without fused multiply-add contraction, as in
+ * the reference; BVH boxes are binary32 rounded outward.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+#define RT_MISS 0xFFFFFFFFu
+#define RT_NONE 0xFFFFFFFFu
+
+enum RtError {
+    RT_OK = 0,
+    RT_E_INVALID = -1,   /* bad argument / malformed scene description */
+    RT_E_DEVICE = -2,    /* HIP runtime error (no device, launch failure, ...) */
+    RT_E_NOMEM = -3,     /* host or device allocation failed */
+    RT_E_UNSUPPORTED = -4
+};
+
+/* ---- flattened scene ---------------------------------------------------- */
+
+/* One 32-byte entry of the traversal stream. The stream is the depth-first,
+ * left-then-right linearisation of the reference's object tree, so walking it
+ * front to back visits objects in the order BVHNode::hit (src/bvh.rs:101-111)
+ * and HittableList::hit (src/hittable.rs:151-164) do.
+ *   meta = kind | index << 4
+ *   RT_N_INNER   : lo/hi = box of a BVHNode (src/bvh.rs:14), link = entry to
+ *                  continue at when the box is missed (one past its subtree)
+ *   RT_N_SPHERE .. RT_N_TRIANGLE : index into the matching primitive table
+ *   RT_N_XF_ENTER: index into xforms; the ray is moved into the wrapper's
+ *                  object space (src/hittable.rs:278-282, 355-368)
+ *   RT_N_XF_EXIT : index of the wrapper being left
+ *   RT_N_MEDIUM  : index into media; entries [i+1, link) are the boundary
+ *                  object (src/constant_medium.rs:11), queried twice
+ * lo/hi are unused (0) except for RT_N_INNER. */
+typedef struct RtNode {
+    float lo[3];
+    float hi[3];
+    uint32_t meta;
+    uint32_t link;
+} RtNode;
+
+enum RtNodeKind {
+    RT_N_INNER = 0, RT_N_SPHERE = 1, RT_N_MSPHERE = 2, RT_N_RECT = 3, RT_N_BOX6 = 4,
+    RT_N_TRIANGLE = 5, RT_N_XF_ENTER = 6, RT_N_XF_EXIT = 7, RT_N_MEDIUM = 8
+};
+
+typedef struct RtSphere {        /* src/hittable.rs:48-52 */
+    double c[3]; double r; uint32_t mat; uint32_t prim_id;
+} RtSphere;
+typedef struct RtMovingSphere {  /* src/hittable.rs:187-194 */
+    double c0[3]; double c1[3]; double t0, t1, r; uint32_t mat; uint32_t prim_id;
+} RtMovingSphere;
+typedef struct RtRect {          /* src/aarect.rs:7-14, 58-65, 109-116; axis 0 = XY (z=k), 1 = XZ (y=k), 2 = YZ (x=k) */
+    double a0, a1, b0, b1, k; uint32_t axis; uint32_t mat; uint32_t prim_id; uint32_t _pad;
+} RtRect;
+typedef struct RtBox6 {          /* src/box6.rs:9-13; the six sides are implied, in src/box6.rs:22-71 order */
+    double p0[3]; double p1[3]; uint32_t mat; uint32_t prim_id;
+} RtBox6;
+typedef struct RtTriangle {      /* src/triangle.rs:7-12 with e1 = point1 - point0, e2 = point2 - point0 (:27-28) */
+    double p0[3]; double e1[3]; double e2[3]; uint32_t mat; uint32_t prim_id;
+} RtTriangle;
+typedef struct RtXform {         /* src/hittable.rs:262-265 (kind 0, Translate), 306-312 (kind 1, RotateY) */
+    uint32_t kind; uint32_t depth;   /* depth = number of wrappers from the outermost down to this one */
+    uint32_t anc[4];                 /* xform indices, outermost first; anc[depth-1] is this entry */
+    uint32_t inst_id; uint32_t _pad;
+    double sin_theta, cos_theta; double offset[3];
+} RtXform;
+typedef struct RtMedium {        /* src/constant_medium.rs:10-14 */
+    double neg_inv_density; uint32_t mat; uint32_t rng_id; uint32_t prim_id; uint32_t _pad;
+} RtMedium;
+
+enum RtMaterialKind { RT_M_LAMBERTIAN = 0, RT_M_METAL = 1, RT_M_DIELECTRIC = 2, RT_M_DIFFUSE_LIGHT = 3, RT_M_ISOTROPIC = 4 };
+typedef struct RtMaterial {      /* src/material.rs:22-24, 53-56, 86-88, 150-152, 181-183 */
+    uint32_t kind; uint32_t tex;     /* tex: albedo / emit texture (Lambertian, DiffuseLight, Isotropic) */
+    double albedo[3];                /* Metal */
+    double param;                    /* Metal: fuzz (already clamped to <= 1), Dielectric: ref_idx */
+} RtMaterial;
+
+enum RtTextureKind { RT_T_SOLID = 0, RT_T_CHECKER = 1, RT_T_NOISE = 2, RT_T_IMAGE = 3 };
+typedef struct RtTexture {       /* src/texture.rs:12-14, 28-31, 53-56, 75-79 */
+    uint32_t kind; uint32_t aux;     /* aux: Noise -> perlin index, Image -> image index */
+    double a[3];                     /* Solid: colour; Checker: even colour; Noise: a[0] = scale */
+    double b[3];                     /* Checker: odd colour */
+} RtTexture;
+typedef struct RtPerlin {        /* src/perlin.rs:6-11 */
+    double ran_vec[256][3]; int32_t perm_x[256]; int32_t perm_y[256]; int32_t perm_z[256];
+} RtPerlin;
+typedef struct RtImage {         /* src/texture.rs:75-79; texels are RGB u8 rows, top row first */
+    uint32_t width, height; uint64_t offset;   /* byte offset into RtSceneDesc.texels */
+} RtImage;
+
+typedef struct RtSceneDesc {
+    uint32_t abi_version; uint32_t _pad;
+    const RtNode* nodes; uint64_t n_nodes;
+    const RtSphere* spheres; uint64_t n_spheres;
+    const RtMovingSphere* msphere; uint64_t n_msphere;
+    const RtRect* rects; uint64_t n_rects;
+    const RtBox6* boxes; uint64_t n_boxes;
+    const RtTriangle* triangles; uint64_t n_triangles;
+    const RtXform* xforms; uint64_t n_xforms;
+    const RtMedium* media; uint64_t n_media;
+    const RtMaterial* materials; uint64_t n_materials;
+    const RtTexture* textures; uint64_t n_textures;
+    const RtPerlin* perlins; uint64_t n_perlins;
+    const RtImage* images; uint64_t n_images;
+    const uint8_t* texels; uint64_t n_texel_bytes;
+} RtSceneDesc;
+
+/* ---- rays, hits, camera, parameters ------------------------------------- */
+
+typedef struct RtRay {           /* src/ray.rs:3-7 + the t range of Hittable::hit + the RNG key of the path */
+    double o[3]; double d[3]; double tm; double tmin; double tmax;
+    uint32_t pixel, sample, bounce, _pad;   /* keys the ConstantMedium draw (src/constant_medium.rs:69) */
+} RtRay;
+
+/* sub = box side (bits 0-7, src/box6.rs:22-71 order) | (inst_id + 1) << 8, where
+ * inst_id is the creation-order id of the innermost Translate/RotateY around the
+ * primitive (0 in those bits when there is none). prim_id = RT_MISS on a miss. */
+typedef struct RtHit {
+    uint32_t prim_id; uint32_t sub; double t; double u; double v;
+} RtHit;
+
+typedef struct RtHitRecord {     /* src/hittable.rs:11-19 as ray_color sees it after world.hit */
+    double p[3]; double normal[3]; double t, u, v;
+    uint32_t prim_id, sub, mat, front_face;
+} RtHitRecord;
+
+typedef struct RtCamera {        /* src/camera.rs:6-17 (without the unused _w) */
+    double orig[3]; double lower_left_corner[3]; double horizontal[3]; double vertical[3];
+    double u[3]; double v[3]; double lens_radius, time0, time1;
+} RtCamera;
+
+typedef struct RtRenderParams {
+    uint32_t width, height;          /* src/main.rs:164-165 */
+    uint32_t sample_begin, sample_end;   /* samples [begin, end) of every pixel (src/main.rs:205) */
+    uint32_t max_depth;              /* src/main.rs:49 */
+    uint32_t samples_per_batch;      /* 0 = library default; samples of every pixel traced per wavefront batch */
+    uint64_t seed;
+    double background[3];            /* src/main.rs:62-162 */
+} RtRenderParams;
+
+typedef struct RtTraceStats {
+    double ms_kernel;                /* device time of the traversal kernel */
+} RtTraceStats;
+
+typedef struct RtRenderStats {
+    uint64_t paths;                  /* path samples started */
+    uint64_t rays;                   /* closest-hit queries issued (all bounces) */
+    double ms_total;                 /* device time of the whole call, all kernels */
+    double ms_extend;                /* device time inside the extend (closest-hit) kernel */
+    double ms_shade;                 /* device time inside the shade kernel */
+    uint32_t batches; uint32_t _pad;
+} RtRenderStats;
+
+typedef struct RtScene RtScene;
+
+/* ---- entry points -------------------------------------------------------- */
+
+uint32_t rt_abi_version(void);
+const char* rt_last_error(void);
+int rt_device_count(void);
+
+/* Replaces the shallow Arc clone of the world into each render thread
+ * (src/main.rs:198): copies the tables to the HBM of the current HIP device. */
+int rt_scene_create(const RtSceneDesc* desc, RtScene** out);
+void rt_scene_destroy(RtScene* scene);
+
+/* Replaces `world.hit(r, t_min, t_max, &mut rec)` (src/color.rs:41 ->
+ * src/bvh.rs:101-111) for n independent rays. Host buffers. */
+int rt_trace_closest(RtScene* scene, const RtRay* rays, uint64_t n, RtHit* out, RtTraceStats* stats);
+/* Same, also returning p / normal / front_face / material as ray_color uses them. */
+int rt_trace_records(RtScene* scene, const RtRay* rays, uint64_t n, RtHitRecord* out);
+/* Same as rt_trace_closest with rays and hits already resident in device memory;
+ * `stream` is a hipStream_t (NULL = default stream). Asynchronous. */
+int rt_trace_closest_device(RtScene* scene, const RtRay* rays_dev, uint64_t n, RtHit* out_dev, void* stream);
+
+/* Replaces the per-pixel sample loop (src/main.rs:201-211): for every pixel adds
+ * the sum of ray_color over samples [sample_begin, sample_end) to
+ * accum_rgb[(y*width + x)*3 + c]. rt_render takes a host buffer (W*H*3 floats,
+ * read-modify-write); rt_render_device takes a device buffer and a hipStream_t,
+ * returns once the work is enqueued unless `stats` is non-NULL (then it waits). */
+int rt_render(RtScene* scene, const RtCamera* cam, const RtRenderParams* params, float* accum_rgb, RtRenderStats* stats);
+int rt_render_device(RtScene* scene, const RtCamera* cam, const RtRenderParams* params, float* accum_rgb_dev, void* stream,
+                     RtRenderStats* stats);
+
+/* Replaces the gamma / clamp / u8 conversion (src/main.rs:212-225): out =
+ * clamp(sqrt(accum / spp), 0, 0.999) * 255 as u8. Host buffers / device buffers. */
+int rt_resolve_u8(const float* accum_rgb, uint32_t width, uint32_t height, uint64_t spp, uint8_t* rgb_out);
+int rt_resolve_u8_device(const float* accum_rgb_dev, uint32_t width, uint32_t height, uint64_t spp, uint8_t* rgb_out_dev,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */
