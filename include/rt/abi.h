@@ -194,13 +194,18 @@ int rt_scene_create(const RtSceneDesc* desc, RtScene** out);
 void rt_scene_destroy(RtScene* scene);
 
 /* Replaces `world.hit(r, t_min, t_max, &mut rec)` (src/color.rs:41 ->
- * src/bvh.rs:101-111) for n independent rays. Host buffers. */
-int rt_trace_closest(RtScene* scene, const RtRay* rays, uint64_t n, RtHit* out, RtTraceStats* stats);
+ * src/bvh.rs:101-111) for n independent rays. `seed` keys the ConstantMedium
+ * draws together with each ray's (pixel, sample, bounce). Host buffers. */
+int rt_trace_closest(RtScene* scene, const RtRay* rays, uint64_t n, uint64_t seed, RtHit* out, RtTraceStats* stats);
 /* Same, also returning p / normal / front_face / material as ray_color uses them. */
-int rt_trace_records(RtScene* scene, const RtRay* rays, uint64_t n, RtHitRecord* out);
+int rt_trace_records(RtScene* scene, const RtRay* rays, uint64_t n, uint64_t seed, RtHitRecord* out);
 /* Same as rt_trace_closest with rays and hits already resident in device memory;
  * `stream` is a hipStream_t (NULL = default stream). Asynchronous. */
-int rt_trace_closest_device(RtScene* scene, const RtRay* rays_dev, uint64_t n, RtHit* out_dev, void* stream);
+int rt_trace_closest_device(RtScene* scene, const RtRay* rays_dev, uint64_t n, uint64_t seed, RtHit* out_dev, void* stream);
+/* Instrumented rt_trace_closest: also counts the traversal work of the whole call.
+ * work[0] = stream entries fetched, work[1 + k] = entries of RtNodeKind k visited
+ * (k = RT_N_INNER counts box tests). 10 words. */
+int rt_trace_work(RtScene* scene, const RtRay* rays, uint64_t n, uint64_t seed, RtHit* out, uint64_t* work);
 
 /* Replaces the per-pixel sample loop (src/main.rs:201-211): for every pixel adds
  * the sum of ray_color over samples [sample_begin, sample_end) to

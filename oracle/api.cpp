@@ -310,10 +310,7 @@ int orc_rotate_y(OrcBuilder* b, int obj, double angle) {
 int orc_constant_medium(OrcBuilder* b, int boundary, double density, int tex) {
     CHK(b->obj, boundary) CHK(b->tex, tex)
     B_ENTER
-    auto m = mk<ConstantMedium>(b->obj[(size_t)boundary], density, b->tex[(size_t)tex]);
-    m->phase_function->mat_id = (uint32_t)b->mat.size();
-    b->mat.push_back(m->phase_function);
-    push_obj(b, m);
+    push_obj(b, mk<ConstantMedium>(b->obj[(size_t)boundary], density, b->tex[(size_t)tex]));
     B_LEAVE return (int)b->obj.size() - 1;
 }
 int orc_list_new(OrcBuilder* b) { b->lists.push_back(std::make_shared<HittableList>()); return (int)b->lists.size() - 1; }

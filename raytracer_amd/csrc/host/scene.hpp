@@ -1,0 +1,624 @@
+// Host-side scene object model: the reference's three traits and their
+// constructors restated in C++, with `hit`/`scatter`/`value` removed (those run on
+// the GPU) and one added method per trait that writes the object into the flat
+// tables of include/rt/abi.h:
+//     Hittable::flatten   <- trait Hittable  (src/hittable.rs:43-46)
+//     Material::describe  <- trait Material  (src/material.rs:8-20)
+//     Texture::describe   <- trait Texture   (src/texture.rs:8-10)
+// bounding_box keeps the reference's exact arithmetic because BVHNode::new
+// (src/bvh.rs:17-98) sorts and bounds with it.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/rt/abi.h"
+#include "../rng.h"
+
+namespace rth {
+
+constexpr double INF = std::numeric_limits<double>::infinity();
+constexpr double PI = 3.14159265358979323846264338327950288;  // src/rtweekend.rs:4
+
+// ---- math (src/vec3.rs) ----------------------------------------------------
+struct Vec3 {
+    double x = 0, y = 0, z = 0;
+    Vec3() = default;
+    Vec3(double a, double b, double c) : x(a), y(b), z(c) {}
+    double operator[](int i) const { return i == 1 ? y : (i == 2 ? z : x); }  // src/vec3.rs:252-262
+    double& at(int i) { return i == 0 ? x : (i == 1 ? y : z); }
+    double squared_length() const { return x * x + y * y + z * z; }     // :27-29
+    double length() const { return std::sqrt(x * x + y * y + z * z); }  // :277-279
+    Vec3 unit() const {                                                  // :283-294
+        double len = length();
+        if (len == 0.0) throw std::domain_error("unit() of a zero-length vector");
+        return Vec3(x / len, y / len, z / len);
+    }
+};
+using Point = Vec3;
+using Color = Vec3;
+inline Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec3 operator*(Vec3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline Vec3 operator/(Vec3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+inline Vec3 elemul(Vec3 a, Vec3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }  // :224-230
+inline Vec3 cross(Vec3 a, Vec3 b) {                                                // :232-238
+    return {a.y * b.z - a.z * b.y, b.x * a.z - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+inline void put3(double* d, Vec3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+
+// ---- per-scene construction state ------------------------------------------
+// The scene stream of the counter-based RNG and the creation-order id counters.
+struct SceneCtx {
+    rt::Rng rng;
+    uint32_t next_prim = 0, next_inst = 0, next_medium = 0;
+    explicit SceneCtx(uint64_t seed) { rng.set_scene(seed); }
+};
+inline thread_local SceneCtx* g_ctx = nullptr;
+struct CtxScope {
+    SceneCtx* prev;
+    explicit CtxScope(SceneCtx* c) : prev(g_ctx) { g_ctx = c; }
+    ~CtxScope() { g_ctx = prev; }
+};
+inline SceneCtx& ctx() {
+    if (!g_ctx) throw std::logic_error("scene objects must be created inside a scene context");
+    return *g_ctx;
+}
+inline double random_double(double min, double max) { return ctx().rng.uniform(min, max); }  // src/rtweekend.rs:11-14
+inline int random_int(int min, int max) { return (int)random_double((double)min, (double)(max + 1)); }  // :17-20
+inline Vec3 random_vec3(double min, double max) {  // Vec3::random, src/vec3.rs:31-37
+    double a = random_double(min, max), b = random_double(min, max), c = random_double(min, max);
+    return {a, b, c};
+}
+inline double degrees_to_radians(double degrees) { return degrees * PI / 180.0; }  // src/rtweekend.rs:6-8
+
+// ---- boxes (src/aabb.rs) ----------------------------------------------------
+struct AABB {
+    Point _min{1, 1, 1}, _max{1, 1, 1};
+};
+inline AABB surrounding_box(const AABB& a, const AABB& b) {  // :33-50
+    AABB r;
+    r._min = {std::fmin(a._min.x, b._min.x), std::fmin(a._min.y, b._min.y), std::fmin(a._min.z, b._min.z)};
+    r._max = {std::fmax(a._max.x, b._max.x), std::fmax(a._max.y, b._max.y), std::fmax(a._max.z, b._max.z)};
+    return r;
+}
+inline float f32_down(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+inline float f32_up(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+
+// ---- flat table builder ----------------------------------------------------
+struct Flat {
+    std::vector<RtNode> nodes;
+    std::vector<RtSphere> spheres;
+    std::vector<RtMovingSphere> msphere;
+    std::vector<RtRect> rects;
+    std::vector<RtBox6> boxes;
+    std::vector<RtTriangle> triangles;
+    std::vector<RtXform> xforms;
+    std::vector<RtMedium> media;
+    std::vector<RtMaterial> materials;
+    std::vector<RtTexture> textures;
+    std::vector<RtPerlin> perlins;
+    std::vector<RtImage> images;
+    std::vector<uint8_t> texels;
+    std::unordered_map<const void*, uint32_t> seen;  // object -> table index, so shared objects are stored once
+    std::vector<uint32_t> xf_stack;
+    bool in_medium = false;
+
+    uint32_t push_node(uint32_t kind, uint32_t index, uint32_t link = 0) {
+        if (index >= (1u << 28)) throw std::length_error("table index exceeds 28 bits");
+        RtNode n{};
+        n.meta = kind | (index << 4);
+        n.link = link;
+        nodes.push_back(n);
+        return (uint32_t)nodes.size() - 1;
+    }
+};
+
+struct Texture {
+    virtual ~Texture() = default;
+    virtual uint32_t describe(Flat& f) const = 0;
+};
+using TexPtr = std::shared_ptr<Texture>;
+
+struct SolidColor : Texture {  // src/texture.rs:12-26
+    Color color_value;
+    explicit SolidColor(Color c) : color_value(c) {}
+    uint32_t describe(Flat& f) const override {
+        auto it = f.seen.find(this);
+        if (it != f.seen.end()) return it->second;
+        RtTexture t{};
+        t.kind = RT_T_SOLID;
+        put3(t.a, color_value);
+        f.textures.push_back(t);
+        return f.seen[this] = (uint32_t)f.textures.size() - 1;
+    }
+};
+
+struct CheckerTexture : Texture {  // src/texture.rs:28-51: even = c1, odd = c2
+    Color even, odd;
+    CheckerTexture(Color c1, Color c2) : even(c1), odd(c2) {}
+    uint32_t describe(Flat& f) const override {
+        auto it = f.seen.find(this);
+        if (it != f.seen.end()) return it->second;
+        RtTexture t{};
+        t.kind = RT_T_CHECKER;
+        put3(t.a, even);
+        put3(t.b, odd);
+        f.textures.push_back(t);
+        return f.seen[this] = (uint32_t)f.textures.size() - 1;
+    }
+};
+
+struct Perlin {  // src/perlin.rs:6-42
+    RtPerlin tab;
+    static void permute(int32_t* tmp, int n) {  // :14-20
+        for (int k = 0; k < n - 1; ++k) {
+            int i = n - 1 - k;
+            int target = random_int(0, i);
+            std::swap(tmp[i], tmp[target]);
+        }
+    }
+    static void generate_perm(int32_t* tmp) {  // :21-30
+        for (int i = 0; i < 256; ++i) tmp[i] = i;
+        permute(tmp, 256);
+    }
+    Perlin() {  // :31-42
+        for (int i = 0; i < 256; ++i) put3(tab.ran_vec[i], random_vec3(-1.0, 1.0).unit());
+        generate_perm(tab.perm_x);
+        generate_perm(tab.perm_y);
+        generate_perm(tab.perm_z);
+    }
+};
+
+struct NoiseTexture : Texture {  // src/texture.rs:53-73
+    Perlin noise;
+    double scale;
+    explicit NoiseTexture(double sc) : noise(), scale(sc) {}
+    uint32_t describe(Flat& f) const override {
+        auto it = f.seen.find(this);
+        if (it != f.seen.end()) return it->second;
+        f.perlins.push_back(noise.tab);
+        RtTexture t{};
+        t.kind = RT_T_NOISE;
+        t.aux = (uint32_t)f.perlins.size() - 1;
+        t.a[0] = scale;
+        f.textures.push_back(t);
+        return f.seen[this] = (uint32_t)f.textures.size() - 1;
+    }
+};
+
+struct ImageTexture : Texture {  // src/texture.rs:75-90; takes decoded RGB8 rows instead of a file name
+    uint32_t width, height;
+    std::vector<uint8_t> rgb;
+    ImageTexture(const uint8_t* p, uint32_t w, uint32_t h) : width(w), height(h), rgb(p, p + (size_t)w * h * 3) {
+        if (w == 0 || h == 0) throw std::invalid_argument("empty image texture");
+    }
+    uint32_t describe(Flat& f) const override {
+        auto it = f.seen.find(this);
+        if (it != f.seen.end()) return it->second;
+        RtImage im{};
+        im.width = width;
+        im.height = height;
+        im.offset = f.texels.size();
+        f.texels.insert(f.texels.end(), rgb.begin(), rgb.end());
+        f.images.push_back(im);
+        RtTexture t{};
+        t.kind = RT_T_IMAGE;
+        t.aux = (uint32_t)f.images.size() - 1;
+        f.textures.push_back(t);
+        return f.seen[this] = (uint32_t)f.textures.size() - 1;
+    }
+};
+
+struct Material {
+    virtual ~Material() = default;
+    virtual RtMaterial fill(Flat& f) const = 0;
+    uint32_t describe(Flat& f) const {
+        auto it = f.seen.find(this);
+        if (it != f.seen.end()) return it->second;
+        RtMaterial m = fill(f);
+        f.materials.push_back(m);
+        return f.seen[this] = (uint32_t)f.materials.size() - 1;
+    }
+};
+using MatPtr = std::shared_ptr<Material>;
+
+struct Lambertian : Material {  // src/material.rs:22-32
+    TexPtr albedo;
+    explicit Lambertian(Color a) : albedo(std::make_shared<SolidColor>(a)) {}
+    explicit Lambertian(TexPtr a) : albedo(std::move(a)) {}
+    RtMaterial fill(Flat& f) const override { RtMaterial m{}; m.kind = RT_M_LAMBERTIAN; m.tex = albedo->describe(f); return m; }
+};
+struct Metal : Material {  // src/material.rs:53-65 (fuzz clamped to <= 1 at :62)
+    Color albedo;
+    double fuzz;
+    Metal(Color a, double fz) : albedo(a), fuzz(fz < 1.0 ? fz : 1.0) {}
+    RtMaterial fill(Flat&) const override { RtMaterial m{}; m.kind = RT_M_METAL; put3(m.albedo, albedo); m.param = fuzz; return m; }
+};
+struct Dielectric : Material {  // src/material.rs:86-94
+    double ref_idx;
+    explicit Dielectric(double ri) : ref_idx(ri) {}
+    RtMaterial fill(Flat&) const override { RtMaterial m{}; m.kind = RT_M_DIELECTRIC; m.param = ref_idx; return m; }
+};
+struct DiffuseLight : Material {  // src/material.rs:150-164
+    TexPtr emit;
+    explicit DiffuseLight(TexPtr a) : emit(std::move(a)) {}
+    explicit DiffuseLight(Color c) : emit(std::make_shared<SolidColor>(c)) {}
+    RtMaterial fill(Flat& f) const override { RtMaterial m{}; m.kind = RT_M_DIFFUSE_LIGHT; m.tex = emit->describe(f); return m; }
+};
+struct Isotropic : Material {  // src/material.rs:181-193
+    TexPtr albedo;
+    explicit Isotropic(TexPtr a) : albedo(std::move(a)) {}
+    explicit Isotropic(Color c) : albedo(std::make_shared<SolidColor>(c)) {}
+    RtMaterial fill(Flat& f) const override { RtMaterial m{}; m.kind = RT_M_ISOTROPIC; m.tex = albedo->describe(f); return m; }
+};
+
+struct Hittable {
+    virtual ~Hittable() = default;
+    virtual bool bounding_box(double t0, double t1, AABB& out) const = 0;
+    virtual void flatten(Flat& f) const = 0;
+};
+using HitPtr = std::shared_ptr<Hittable>;
+
+struct Sphere : Hittable {  // src/hittable.rs:48-62, 115-121
+    Point center;
+    double radius;
+    MatPtr mat_ptr;
+    uint32_t id;
+    Sphere(Point c, double r, MatPtr m) : center(c), radius(r), mat_ptr(std::move(m)), id(ctx().next_prim++) {}
+    bool bounding_box(double, double, AABB& out) const override {
+        out._min = center - Vec3(radius, radius, radius);
+        out._max = center + Vec3(radius, radius, radius);
+        return true;
+    }
+    void flatten(Flat& f) const override {
+        auto it = f.seen.find(this);
+        uint32_t idx;
+        if (it != f.seen.end()) idx = it->second;
+        else {
+            RtSphere s{};
+            put3(s.c, center); s.r = radius; s.mat = mat_ptr->describe(f); s.prim_id = id;
+            f.spheres.push_back(s);
+            idx = f.seen[this] = (uint32_t)f.spheres.size() - 1;
+        }
+        f.push_node(RT_N_SPHERE, idx);
+    }
+};
+
+struct MovingSphere : Hittable {  // src/hittable.rs:187-212, 248-259
+    Point center0, center1;
+    double time0, time1, radius;
+    MatPtr mat_ptr;
+    uint32_t id;
+    MovingSphere(Point c0, Point c1, double t0, double t1, double r, MatPtr m)
+        : center0(c0), center1(c1), time0(t0), time1(t1), radius(r), mat_ptr(std::move(m)), id(ctx().next_prim++) {}
+    Point center(double time) const { return center0 + (center1 - center0) * ((time - time0) / (time1 - time0)); }
+    bool bounding_box(double t0, double t1, AABB& out) const override {
+        AABB b0, b1;
+        b0._min = center(t0) - Vec3(radius, radius, radius); b0._max = center(t0) + Vec3(radius, radius, radius);
+        b1._min = center(t1) - Vec3(radius, radius, radius); b1._max = center(t1) + Vec3(radius, radius, radius);
+        out = surrounding_box(b0, b1);
+        return true;
+    }
+    void flatten(Flat& f) const override {
+        auto it = f.seen.find(this);
+        uint32_t idx;
+        if (it != f.seen.end()) idx = it->second;
+        else {
+            RtMovingSphere s{};
+            put3(s.c0, center0); put3(s.c1, center1); s.t0 = time0; s.t1 = time1; s.r = radius;
+            s.mat = mat_ptr->describe(f); s.prim_id = id;
+            f.msphere.push_back(s);
+            idx = f.seen[this] = (uint32_t)f.msphere.size() - 1;
+        }
+        f.push_node(RT_N_MSPHERE, idx);
+    }
+};
+
+// XYRect / XZRect / YZRect (src/aarect.rs:7-27, 58-78, 109-129) as one class; axis 0 = XY, 1 = XZ, 2 = YZ.
+struct AARect : Hittable {
+    int axis;
+    double a0, a1, b0, b1, k;
+    MatPtr mp;
+    uint32_t id;
+    AARect(int axis_, double a0_, double a1_, double b0_, double b1_, double k_, MatPtr m)
+        : axis(axis_), a0(a0_), a1(a1_), b0(b0_), b1(b1_), k(k_), mp(std::move(m)), id(ctx().next_prim++) {}
+    bool bounding_box(double, double, AABB& out) const override {  // :49-55, 100-106, 151-157
+        if (axis == 0) { out._min = {a0, b0, k - 0.0001}; out._max = {a1, b1, k + 0.0001}; }
+        else if (axis == 1) { out._min = {a0, k - 0.0001, b0}; out._max = {a1, k + 0.0001, b1}; }
+        else { out._min = {k - 0.0001, a0, b0}; out._max = {k + 0.0001, a1, b1}; }
+        return true;
+    }
+    void flatten(Flat& f) const override {
+        auto it = f.seen.find(this);
+        uint32_t idx;
+        if (it != f.seen.end()) idx = it->second;
+        else {
+            RtRect r{};
+            r.a0 = a0; r.a1 = a1; r.b0 = b0; r.b1 = b1; r.k = k; r.axis = (uint32_t)axis; r.mat = mp->describe(f); r.prim_id = id;
+            f.rects.push_back(r);
+            idx = f.seen[this] = (uint32_t)f.rects.size() - 1;
+        }
+        f.push_node(RT_N_RECT, idx);
+    }
+};
+inline HitPtr XYRect(double x0, double x1, double y0, double y1, double k, MatPtr m) { return std::make_shared<AARect>(0, x0, x1, y0, y1, k, std::move(m)); }
+inline HitPtr XZRect(double x0, double x1, double z0, double z1, double k, MatPtr m) { return std::make_shared<AARect>(1, x0, x1, z0, z1, k, std::move(m)); }
+inline HitPtr YZRect(double y0, double y1, double z0, double z1, double k, MatPtr m) { return std::make_shared<AARect>(2, y0, y1, z0, z1, k, std::move(m)); }
+
+struct Box6 : Hittable {  // src/box6.rs:9-85; the six rects of :22-71 are implied by p0, p1
+    Point box_min, box_max;
+    MatPtr mat;
+    uint32_t id;
+    Box6(Point p0, Point p1, MatPtr m) : box_min(p0), box_max(p1), mat(std::move(m)), id(ctx().next_prim++) {}
+    bool bounding_box(double, double, AABB& out) const override { out._min = box_min; out._max = box_max; return true; }
+    void flatten(Flat& f) const override {
+        auto it = f.seen.find(this);
+        uint32_t idx;
+        if (it != f.seen.end()) idx = it->second;
+        else {
+            RtBox6 b{};
+            put3(b.p0, box_min); put3(b.p1, box_max); b.mat = mat->describe(f); b.prim_id = id;
+            f.boxes.push_back(b);
+            idx = f.seen[this] = (uint32_t)f.boxes.size() - 1;
+        }
+        f.push_node(RT_N_BOX6, idx);
+    }
+};
+
+struct Triangle : Hittable {  // src/triangle.rs:7-23, 70-83 (argument order point1, point2, point0)
+    Point point1, point2, point0;
+    MatPtr mp;
+    uint32_t id;
+    Triangle(Point p1, Point p2, Point p0, MatPtr m) : point1(p1), point2(p2), point0(p0), mp(std::move(m)), id(ctx().next_prim++) {}
+    bool bounding_box(double, double, AABB& out) const override {
+        out._min = {std::fmin(std::fmin(point0.x, point1.x), point2.x), std::fmin(std::fmin(point0.y, point1.y), point2.y),
+                    std::fmin(std::fmin(point0.z, point1.z), point2.z)};
+        out._max = {std::fmax(std::fmax(point0.x, point1.x), point2.x), std::fmax(std::fmax(point0.y, point1.y), point2.y),
+                    std::fmax(std::fmax(point0.z, point1.z), point2.z)};
+        return true;
+    }
+    void flatten(Flat& f) const override {
+        auto it = f.seen.find(this);
+        uint32_t idx;
+        if (it != f.seen.end()) idx = it->second;
+        else {
+            RtTriangle t{};
+            put3(t.p0, point0);
+            put3(t.e1, point1 - point0);  // edge1, src/triangle.rs:27
+            put3(t.e2, point2 - point0);  // edge2, :28
+            t.mat = mp->describe(f); t.prim_id = id;
+            f.triangles.push_back(t);
+            idx = f.seen[this] = (uint32_t)f.triangles.size() - 1;
+        }
+        f.push_node(RT_N_TRIANGLE, idx);
+    }
+};
+
+struct HittableList : Hittable {  // src/hittable.rs:124-185
+    std::vector<HitPtr> objects;
+    void add(HitPtr o) { objects.push_back(std::move(o)); }
+    void clear() { objects.clear(); }
+    bool bounding_box(double t0, double t1, AABB& out) const override {
+        if (objects.empty()) return false;
+        AABB temp;
+        bool first = true;
+        for (const auto& o : objects) {
+            if (!o->bounding_box(t0, t1, temp)) return false;
+            out = first ? temp : surrounding_box(out, temp);
+            first = false;
+        }
+        return true;
+    }
+    // HittableList::hit (:151-164) keeps a running closest t over its objects in order, which is what
+    // walking their entries front to back does.
+    void flatten(Flat& f) const override { for (const auto& o : objects) o->flatten(f); }
+};
+
+inline void push_xform(Flat& f, const RtXform& proto, const Hittable& child) {
+    if (f.xf_stack.size() >= 4) throw std::length_error("more than 4 nested Translate/RotateY wrappers");
+    RtXform x = proto;
+    const uint32_t self = (uint32_t)f.xforms.size();
+    x.depth = (uint32_t)f.xf_stack.size() + 1;
+    for (uint32_t i = 0; i < 4; ++i) x.anc[i] = RT_NONE;
+    for (size_t i = 0; i < f.xf_stack.size(); ++i) x.anc[i] = f.xf_stack[i];
+    x.anc[x.depth - 1] = self;
+    f.xforms.push_back(x);
+    f.push_node(RT_N_XF_ENTER, self);
+    f.xf_stack.push_back(self);
+    child.flatten(f);
+    f.xf_stack.pop_back();
+    f.push_node(RT_N_XF_EXIT, self);
+}
+
+struct Translate : Hittable {  // src/hittable.rs:262-304
+    HitPtr ptr;
+    Vec3 offset;
+    uint32_t id;
+    Translate(HitPtr p, Vec3 displacement) : ptr(std::move(p)), offset(displacement), id(ctx().next_inst++) {}
+    bool bounding_box(double t0, double t1, AABB& out) const override {
+        if (!ptr->bounding_box(t0, t1, out)) return false;
+        out._min = out._min + offset;
+        out._max = out._max + offset;
+        return true;
+    }
+    void flatten(Flat& f) const override {
+        RtXform x{};
+        x.kind = 0; x.inst_id = id; put3(x.offset, offset);
+        push_xform(f, x, *ptr);
+    }
+};
+
+struct RotateY : Hittable {  // src/hittable.rs:306-392
+    HitPtr ptr;
+    double sin_theta, cos_theta;
+    bool hasbox;
+    AABB bbox;
+    uint32_t id;
+    RotateY(HitPtr p, double angle) : ptr(std::move(p)), id(ctx().next_inst++) {  // :315-350
+        double radians = degrees_to_radians(angle);
+        sin_theta = std::sin(radians);
+        cos_theta = std::cos(radians);
+        Point mn(INF, INF, INF), mx(-INF, -INF, -INF);
+        hasbox = ptr->bounding_box(0.0, 1.0, bbox);
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+                for (int k = 0; k < 2; ++k) {
+                    double x = (double)i * bbox._max.x + (double)(1 - i) * bbox._min.x;
+                    double y = (double)j * bbox._max.y + (double)(1 - j) * bbox._min.y;
+                    double z = (double)k * bbox._max.z + (double)(1 - k) * bbox._min.z;
+                    double newx = cos_theta * x + sin_theta * z;
+                    double newz = -sin_theta * x + cos_theta * z;
+                    Vec3 tester(newx, y, newz);
+                    for (int c = 0; c < 3; ++c) {
+                        mn.at(c) = std::fmin(mn[c], tester[c]);
+                        mx.at(c) = std::fmax(mx[c], tester[c]);
+                    }
+                }
+        bbox._min = mn;
+        bbox._max = mx;
+    }
+    bool bounding_box(double, double, AABB& out) const override { out = bbox; return hasbox; }
+    void flatten(Flat& f) const override {
+        RtXform x{};
+        x.kind = 1; x.inst_id = id; x.sin_theta = sin_theta; x.cos_theta = cos_theta;
+        push_xform(f, x, *ptr);
+    }
+};
+
+struct ConstantMedium : Hittable {  // src/constant_medium.rs:10-31, 91-93
+    HitPtr boundary;
+    MatPtr phase_function;
+    double neg_inv_density;
+    uint32_t id, rng_id;
+    ConstantMedium(HitPtr b, double d, TexPtr a)
+        : boundary(std::move(b)), phase_function(std::make_shared<Isotropic>(std::move(a))), neg_inv_density(-1.0 / d),
+          id(ctx().next_prim++), rng_id(ctx().next_medium++) {}
+    ConstantMedium(HitPtr b, double d, Color c)
+        : boundary(std::move(b)), phase_function(std::make_shared<Isotropic>(c)), neg_inv_density(-1.0 / d),
+          id(ctx().next_prim++), rng_id(ctx().next_medium++) {}
+    bool bounding_box(double t0, double t1, AABB& out) const override { return boundary->bounding_box(t0, t1, out); }
+    void flatten(Flat& f) const override {
+        if (f.in_medium) throw std::invalid_argument("a ConstantMedium inside the boundary of another is not supported");
+        if (rng_id >= 0xFFF0u) throw std::length_error("too many ConstantMedium objects");
+        auto it = f.seen.find(this);
+        uint32_t idx;
+        if (it != f.seen.end()) idx = it->second;
+        else {
+            RtMedium m{};
+            m.neg_inv_density = neg_inv_density; m.mat = phase_function->describe(f); m.rng_id = rng_id; m.prim_id = id;
+            f.media.push_back(m);
+            idx = f.seen[this] = (uint32_t)f.media.size() - 1;
+        }
+        const uint32_t at = f.push_node(RT_N_MEDIUM, idx);
+        f.in_medium = true;
+        boundary->flatten(f);
+        f.in_medium = false;
+        f.nodes[at].link = (uint32_t)f.nodes.size();
+    }
+};
+
+struct BVHNode : Hittable {  // src/bvh.rs:10-15
+    HitPtr left, right;
+    AABB _box;
+    bool bounding_box(double, double, AABB& out) const override { out = _box; return true; }  // :113-116
+    void flatten(Flat& f) const override {
+        const uint32_t at = f.push_node(RT_N_INNER, 0);
+        RtNode& n = f.nodes[at];
+        // A box that is flat on an axis is never hit by the reference's test (src/aabb.rs:25, t1 <= t0);
+        // rounding it outward to f32 could give it thickness, so it is stored inverted instead.
+        bool flat = false;
+        for (int a = 0; a < 3; ++a) flat = flat || (_box._min[a] == _box._max[a]);
+        for (int a = 0; a < 3; ++a) {
+            n.lo[a] = flat ? std::numeric_limits<float>::infinity() : f32_down(_box._min[a]);
+            n.hi[a] = flat ? -std::numeric_limits<float>::infinity() : f32_up(_box._max[a]);
+        }
+        left->flatten(f);
+        // A span-1 node holds the same object twice (src/bvh.rs:39-44); hitting it a second time with
+        // t_max = rec.t changes nothing, so it is emitted once.
+        if (right.get() != left.get()) right->flatten(f);
+        f.nodes[at].link = (uint32_t)f.nodes.size();
+    }
+    static std::shared_ptr<BVHNode> create(HittableList& list, double time0, double time1);  // BVHNode::new, :94-97
+};
+
+// box_compare (src/bvh.rs:119-134) keys on bounding_box(0, 0)._min[axis].
+inline double box_key(const HitPtr& o, int axis) {
+    AABB b;
+    if (!o->bounding_box(0.0, 0.0, b)) throw std::runtime_error("object without a bounding box in BVHNode::new");  // :123-125
+    return b._min[axis];
+}
+
+inline std::shared_ptr<BVHNode> new_from_list(std::vector<HitPtr>& objects, size_t start, size_t end, double time0,
+                                              double time1) {  // src/bvh.rs:17-91
+    const int axis = random_int(0, 2);  // drawn for every node, also span 1 and 2 (:24)
+    const size_t span = end - start;
+    auto node = std::make_shared<BVHNode>();
+    if (span == 1) {
+        node->left = node->right = objects[start];
+    } else if (span == 2) {
+        if (box_key(objects[start + 1], axis) < box_key(objects[start], axis)) {  // Ordering::Greater (:54-60)
+            node->left = objects[start + 1];
+            node->right = objects[start];
+        } else {
+            node->left = objects[start];
+            node->right = objects[start + 1];
+        }
+    } else {
+        // slice::sort_by(comparator) is a stable sort (:70). Keys are extracted once per level; a stable
+        // sort by key gives the same permutation as the comparator-based one.
+        std::vector<std::pair<double, HitPtr>> keyed;
+        keyed.reserve(span);
+        for (size_t i = start; i < end; ++i) keyed.emplace_back(box_key(objects[i], axis), std::move(objects[i]));
+        std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        for (size_t i = 0; i < span; ++i) objects[start + i] = std::move(keyed[i].second);
+        const size_t mid = start + span / 2;
+        node->left = new_from_list(objects, start, mid, time0, time1);
+        node->right = new_from_list(objects, mid, end, time0, time1);
+    }
+    AABB bl, br;
+    if (!node->left->bounding_box(time0, time1, bl) || !node->right->bounding_box(time0, time1, br))
+        throw std::runtime_error("object without a bounding box in BVHNode::new");  // :83-87
+    node->_box = surrounding_box(bl, br);
+    return node;
+}
+
+inline std::shared_ptr<BVHNode> BVHNode::create(HittableList& list, double time0, double time1) {
+    if (list.objects.empty()) throw std::invalid_argument("BVHNode::new on an empty list");
+    return new_from_list(list.objects, 0, list.objects.size(), time0, time1);
+}
+
+// ---- camera (src/camera.rs:27-59) -------------------------------------------
+inline RtCamera camera_new(Point lookfrom, Point lookat, Vec3 vup, double vfov, double aspect_ratio, double aperture,
+                           double focus_dist, double t0, double t1) {
+    const double theta = degrees_to_radians(vfov);
+    const double h = std::tan(theta / 2.0);
+    const double viewport_height = 2.0 * h;
+    const double viewport_width = aspect_ratio * viewport_height;
+    const Vec3 w = (lookfrom - lookat).unit();
+    const Vec3 u = cross(vup, w).unit();
+    const Vec3 v = cross(w, u);
+    const Vec3 horizontal = u * focus_dist * viewport_width;
+    const Vec3 vertical = v * focus_dist * viewport_height;
+    const Vec3 llc = lookfrom - horizontal / 2.0 - vertical / 2.0 - w * focus_dist;
+    RtCamera c{};
+    put3(c.orig, lookfrom); put3(c.lower_left_corner, llc); put3(c.horizontal, horizontal); put3(c.vertical, vertical);
+    put3(c.u, u); put3(c.v, v);
+    c.lens_radius = aperture / 2.0; c.time0 = t0; c.time1 = t1;
+    return c;
+}
+
+}  // namespace rth

@@ -1,0 +1,324 @@
+// The reference's scene library (src/main.rs:244-765) and per-scene constants
+// (src/main.rs:55-179) on the host object model of scene.hpp. Every random draw
+// comes from the seeded scene stream, in the reference's call order (Rust
+// evaluates arguments left to right; draws are named here because C++ does not).
+#include "scenes.hpp"
+
+namespace rth {
+
+template <class T, class... A>
+static std::shared_ptr<T> mk(A&&... a) { return std::make_shared<T>(std::forward<A>(a)...); }
+
+bool scene_setup(int scene, RtSceneSetup& s) {  // src/main.rs:55-162
+    s = RtSceneSetup{};
+    put3(s.lookfrom, {13.0, 2.0, 3.0}); put3(s.lookat, {0.0, 0.0, 0.0}); put3(s.vup, {0.0, 1.0, 0.0});
+    s.vfov = 40.0; s.aspect_ratio = 3.0 / 2.0; s.aperture = 0.0; s.focus_dist = 10.0; s.time0 = 0.0; s.time1 = 1.0;
+    put3(s.background, {0.0, 0.0, 0.0});
+    s.samples_per_pixel = 64; s.width = 800;
+    switch (scene) {
+        case RT_SCENE_RANDOM: put3(s.background, {0.7, 0.8, 1.0}); s.vfov = 20.0; s.aperture = 0.1; return true;
+        case RT_SCENE_RANDOM_PINHOLE: put3(s.background, {0.7, 0.8, 1.0}); s.vfov = 20.0; return true;
+        case RT_SCENE_SIMPLE_LIGHT:
+            s.samples_per_pixel = 400; put3(s.lookfrom, {26.0, 3.0, 6.0}); put3(s.lookat, {0.0, 2.0, 0.0}); s.vfov = 20.0; return true;
+        case RT_SCENE_LIGHT_DEMO:
+            put3(s.lookfrom, {13.0, 5.0, 10.0}); s.focus_dist = 15.0; s.aperture = 0.4; s.vfov = 40.0; s.samples_per_pixel = 300; return true;
+        case RT_SCENE_TWO_PERLIN: case RT_SCENE_EARTH: s.vfov = 20.0; put3(s.background, {0.5, 0.8, 0.8}); return true;
+        case RT_SCENE_CORNELL: case RT_SCENE_CORNELL_SMOKE:
+            s.aspect_ratio = 1.0; s.samples_per_pixel = 200; put3(s.lookfrom, {278.0, 278.0, -800.0});
+            put3(s.lookat, {278.0, 278.0, 0.0}); s.vfov = 40.0; return true;
+        case RT_SCENE_FINAL:
+            s.aspect_ratio = 1.0; s.samples_per_pixel = 1000; put3(s.lookfrom, {478.0, 278.0, -600.0});
+            put3(s.lookat, {278.0, 278.0, 0.0}); s.vfov = 40.0; return true;
+        case RT_SCENE_TRIANGLE:
+            s.aspect_ratio = 1.0; s.samples_per_pixel = 256; put3(s.background, {0.52, 0.80, 0.92});
+            put3(s.lookfrom, {3.0, 2.0, -7.0}); s.vfov = 40.0; return true;
+        case RT_SCENE_KALEIDOSCOPE: case RT_SCENE_KALEIDOSCOPE_MESH:
+            s.aspect_ratio = 1.0; s.samples_per_pixel = 256; put3(s.background, {0.52, 0.80, 0.92});
+            put3(s.lookfrom, {1.5, -2.4, -0.866}); put3(s.vup, {0.0, 0.0, -1.0}); put3(s.lookat, {1.5, 0.0, -0.866});
+            s.vfov = 70.0; return true;
+    }
+    return false;
+}
+
+static MatPtr checker_ground() {  // src/main.rs:246-250
+    return mk<Lambertian>(TexPtr(mk<CheckerTexture>(Color(0.2, 0.3, 0.1), Color(0.9, 0.9, 0.9))));
+}
+
+static TexPtr earth_texture(const SceneOptions& o) {  // ImageTexture::new("image_texture/earthmap.jpg"), src/main.rs:445,665
+    static const uint8_t grey[12] = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
+    if (o.image_rgb) return mk<ImageTexture>(o.image_rgb, o.image_w, o.image_h);
+    return mk<ImageTexture>(grey, 2u, 2u);
+}
+
+static HitPtr random_scene(const SceneOptions& o) {  // src/main.rs:244-316
+    HittableList world;
+    world.add(mk<Sphere>(Point(0.0, -1000.0, 0.0), 1000.0, checker_ground()));
+    for (int a = -11; a < 11; ++a) {
+        for (int b = -11; b < 11; ++b) {
+            const double choose_mat = random_double(0.0, 1.0);
+            const double cx = (double)a + 0.9 * random_double(0.0, 1.0);
+            const double cz = (double)b + 0.9 * random_double(0.0, 1.0);
+            const Point center(cx, 0.2, cz);
+            if ((center - Point(4.0, 0.2, 0.0)).length() <= 0.9) continue;
+            if (choose_mat < 0.8) {  // diffuse, moving
+                const Color c1 = random_vec3(0.0, 1.0);
+                const Color c2 = random_vec3(0.0, 1.0);
+                MatPtr sphere_material = mk<Lambertian>(elemul(c1, c2));
+                const Point center2 = center + Vec3(0.0, random_double(0.0, 0.5), 0.0);
+                world.add(mk<MovingSphere>(center, center2, 0.0, 1.0, 0.2, sphere_material));
+            } else if (choose_mat < 0.95) {  // metal
+                const Color albedo = random_vec3(0.5, 1.0);
+                const double fuzz = random_double(0.0, 0.5);
+                world.add(mk<Sphere>(center, 0.2, MatPtr(mk<Metal>(albedo, fuzz))));
+            } else {  // glass
+                world.add(mk<Sphere>(center, 0.2, MatPtr(mk<Dielectric>(1.5))));
+            }
+        }
+    }
+    world.add(mk<Sphere>(Point(0.0, 1.0, 0.0), 1.0, MatPtr(mk<Dielectric>(1.5))));
+    world.add(mk<Sphere>(Point(-4.0, 1.0, 0.0), 1.0, MatPtr(mk<Lambertian>(Color(0.4, 0.2, 0.1)))));
+    world.add(mk<Sphere>(Point(4.0, 1.0, 0.0), 1.0, MatPtr(mk<Metal>(Color(0.7, 0.6, 0.5), 0.0))));
+    return BVHNode::create(world, 0.0, o.bvh_shutter_times ? 1.0 : 0.1);
+}
+
+static HitPtr simple_light() {  // src/main.rs:318-344
+    HittableList world;
+    MatPtr ground_material = checker_ground();
+    world.add(mk<Sphere>(Point(0.0, -1000.0, 0.0), 1000.0, ground_material));
+    world.add(mk<Sphere>(Point(0.0, 2.0, 0.0), 2.0, ground_material));
+    MatPtr difflight = mk<DiffuseLight>(TexPtr(mk<SolidColor>(Color(4.0, 4.0, 4.0))));
+    world.add(XYRect(3.0, 5.0, 1.0, 3.0, -2.0, difflight));
+    return BVHNode::create(world, 0.0, 1.0);
+}
+
+static HitPtr light_demo() {  // src/main.rs:346-422
+    HittableList world;
+    world.add(mk<Sphere>(Point(0.0, -1000.0, 0.0), 1000.0, checker_ground()));
+    for (int a = -15; a < 15; ++a) {
+        for (int b = -15; b < 15; ++b) {
+            const double choose_mat = random_double(0.0, 1.0);
+            const double r = random_double(0.1, 0.4);
+            const double cx = (double)a / 1.5 + 0.25 * random_double(0.0, 1.0);
+            const double cz = (double)b / 1.5 + 0.25 * random_double(0.0, 1.0);
+            const Point center(cx, r, cz);
+            const bool keep = (center - Point(0.0, 0.0, 0.0)).length() > 2.0 && (center - Point(2.0, 0.0, 0.0)).length() > 1.3 &&
+                              (center - Point(-2.0, 0.0, 0.0)).length() > 1.3;
+            if (!keep) continue;
+            if (choose_mat < 0.2) {
+                const Color c1 = random_vec3(0.0, 1.0);
+                const Color c2 = random_vec3(0.0, 1.0);
+                world.add(mk<Sphere>(center, r, MatPtr(mk<Lambertian>(elemul(c1, c2)))));
+            } else if (choose_mat < 0.7) {
+                MatPtr difflight = mk<DiffuseLight>(TexPtr(mk<SolidColor>(random_vec3(0.0, 1.0))));
+                world.add(mk<Sphere>(center, r, difflight));
+            } else if (choose_mat < 0.85) {
+                const Color albedo = random_vec3(0.5, 1.0);
+                const double fuzz = random_double(0.0, 0.5);
+                world.add(mk<Sphere>(center, r, MatPtr(mk<Metal>(albedo, fuzz))));
+            } else {
+                world.add(mk<Sphere>(center, r, MatPtr(mk<Dielectric>(1.5))));
+            }
+        }
+    }
+    MatPtr difflight = mk<DiffuseLight>(TexPtr(mk<CheckerTexture>(Color(1.0, 0.5, 0.44), Color(1.0, 0.64, 0.0))));
+    world.add(mk<Sphere>(Point(0.0, 0.9, 0.0), 0.9, difflight));
+    MatPtr material1 = mk<Dielectric>(1.5);
+    MatPtr material3 = mk<Metal>(Color(0.7, 0.6, 0.5), 0.0);
+    world.add(mk<Sphere>(Point(-2.0, 0.65, 0.0), 0.65, material3));
+    world.add(mk<Sphere>(Point(2.0, 0.65, 0.0), 0.65, material1));
+    return BVHNode::create(world, 0.0, 0.1);
+}
+
+static HitPtr two_perlin_spheres() {  // src/main.rs:424-442
+    HittableList world;
+    TexPtr pertext = mk<NoiseTexture>(4.0);
+    world.add(mk<Sphere>(Point(0.0, -1000.0, 0.0), 1000.0, MatPtr(mk<Lambertian>(pertext))));
+    world.add(mk<Sphere>(Point(0.0, 2.0, 0.0), 2.0, MatPtr(mk<Lambertian>(pertext))));
+    return BVHNode::create(world, 0.0, 0.1);
+}
+
+static HitPtr earth(const SceneOptions& o) {  // src/main.rs:444-457
+    MatPtr earth_surface = mk<Lambertian>(earth_texture(o));
+    HittableList world;
+    world.add(mk<Sphere>(Point(0.0, 0.0, 0.0), 2.0, earth_surface));
+    return BVHNode::create(world, 0.0, 1.0);
+}
+
+// The five walls and the ceiling light shared by cornell_box (:461-496) and cornell_smoke (:521-556).
+static MatPtr cornell_room(HittableList& world, double lx0, double lx1, double lz0, double lz1, double emit) {
+    MatPtr red = mk<Lambertian>(Color(0.65, 0.05, 0.05));
+    MatPtr white = mk<Lambertian>(Color(0.73, 0.73, 0.73));
+    MatPtr green = mk<Lambertian>(Color(0.12, 0.45, 0.15));
+    MatPtr light = mk<DiffuseLight>(TexPtr(mk<SolidColor>(Color(emit, emit, emit))));
+    world.add(YZRect(0.0, 555.0, 0.0, 555.0, 555.0, green));
+    world.add(YZRect(0.0, 555.0, 0.0, 555.0, 0.0, red));
+    world.add(XZRect(lx0, lx1, lz0, lz1, 554.0, light));
+    world.add(XZRect(0.0, 555.0, 0.0, 555.0, 0.0, white));
+    world.add(XZRect(0.0, 555.0, 0.0, 555.0, 555.0, white));
+    world.add(XYRect(0.0, 555.0, 0.0, 555.0, 555.0, white));
+    return white;
+}
+
+static HitPtr cornell_block(Point p1, double angle, Vec3 offset, MatPtr white) {  // e.g. src/main.rs:498-504
+    HitPtr b = mk<Box6>(Point(0.0, 0.0, 0.0), p1, white);
+    b = mk<RotateY>(b, angle);
+    b = mk<Translate>(b, offset);
+    return b;
+}
+
+static HitPtr cornell_box() {  // src/main.rs:459-517
+    HittableList world;
+    MatPtr white = cornell_room(world, 213.0, 343.0, 227.0, 332.0, 15.0);
+    world.add(cornell_block(Point(165.0, 330.0, 165.0), 15.0, Vec3(265.0, 0.0, 295.0), white));
+    world.add(cornell_block(Point(165.0, 165.0, 165.0), -18.0, Vec3(130.0, 0.0, 65.0), white));
+    return BVHNode::create(world, 0.0, 1.0);
+}
+
+static HitPtr cornell_smoke() {  // src/main.rs:519-585
+    HittableList world;
+    MatPtr white = cornell_room(world, 113.0, 443.0, 127.0, 432.0, 7.0);
+    HitPtr box1 = cornell_block(Point(165.0, 330.0, 165.0), 15.0, Vec3(265.0, 0.0, 295.0), white);
+    world.add(mk<ConstantMedium>(box1, 0.01, Color(0.0, 0.0, 0.0)));
+    HitPtr box2 = cornell_block(Point(165.0, 165.0, 165.0), -18.0, Vec3(130.0, 0.0, 65.0), white);
+    world.add(mk<ConstantMedium>(box2, 0.01, Color(1.0, 1.0, 1.0)));
+    return BVHNode::create(world, 0.0, 1.0);
+}
+
+static HitPtr final_scene(const SceneOptions& o) {  // src/main.rs:587-699
+    HittableList boxes1;
+    MatPtr ground = mk<Lambertian>(Color(0.48, 0.83, 0.53));
+    const int boxes_per_side = (int)o.boxes_per_side;
+    for (int i = 0; i < boxes_per_side; ++i) {
+        for (int j = 0; j < boxes_per_side; ++j) {
+            const double w = 100.0;
+            const double x0 = -1000.0 + (double)i * w;
+            const double z0 = -1000.0 + (double)j * w;
+            const double y0 = 0.0;
+            const double x1 = x0 + w;
+            const double y1 = random_double(1.0, 101.0);
+            const double z1 = z0 + w;
+            boxes1.add(mk<Box6>(Point(x0, y0, z0), Point(x1, y1, z1), ground));
+        }
+    }
+    HittableList world;
+    world.add(BVHNode::create(boxes1, 0.0, 1.0));
+
+    MatPtr light = mk<DiffuseLight>(Color(7.0, 7.0, 7.0));
+    world.add(XZRect(123.0, 423.0, 147.0, 412.0, 554.0, light));
+
+    const Point center1(400.0, 400.0, 200.0);
+    const Point center2 = center1 + Vec3(30.0, 0.0, 0.0);
+    world.add(mk<MovingSphere>(center1, center2, 0.0, 1.0, 50.0, MatPtr(mk<Lambertian>(Color(0.7, 0.3, 0.1)))));
+
+    world.add(mk<Sphere>(Point(260.0, 150.0, 45.0), 50.0, MatPtr(mk<Dielectric>(1.5))));
+    world.add(mk<Sphere>(Point(0.0, 150.0, 145.0), 50.0, MatPtr(mk<Metal>(Color(0.8, 0.8, 0.9), 10.0))));
+
+    HitPtr boundary = mk<Sphere>(Point(360.0, 150.0, 145.0), 70.0, MatPtr(mk<Dielectric>(1.5)));
+    world.add(boundary);
+    world.add(mk<ConstantMedium>(boundary, 0.02, Color(0.2, 0.4, 0.9)));
+    HitPtr boundary1 = mk<Sphere>(Point(0.0, 0.0, 0.0), 5000.0, MatPtr(mk<Dielectric>(1.5)));
+    world.add(mk<ConstantMedium>(boundary1, 0.0001, Color(1.0, 1.0, 1.0)));
+
+    MatPtr emat = mk<Lambertian>(earth_texture(o));
+    world.add(mk<Sphere>(Point(400.0, 200.0, 400.0), 100.0, emat));
+    TexPtr pertext = mk<NoiseTexture>(0.1);
+    world.add(mk<Sphere>(Point(220.0, 280.0, 300.0), 80.0, MatPtr(mk<Lambertian>(pertext))));
+
+    HittableList boxes2;
+    MatPtr white = mk<Lambertian>(Color(0.73, 0.73, 0.73));
+    const int ns = 100;
+    for (int j = 0; j < ns; ++j) boxes2.add(mk<Sphere>(random_vec3(0.0, 165.0), 10.0, white));
+    HitPtr cluster = BVHNode::create(boxes2, 0.0, 1.0);
+    world.add(mk<Translate>(HitPtr(mk<RotateY>(cluster, 15.0)), Vec3(-100.0, 270.0, 395.0)));
+
+    return BVHNode::create(world, 0.0, 1.0);
+}
+
+static HitPtr try_triangle() {  // src/main.rs:701-738
+    HittableList world;
+    const Point point1(2.0, 0.0, 0.0), point2(-2.0, 0.0, 0.0), point3(1.0, 2.0, 0.0), point4(-2.0, 4.0, -1.0);
+    MatPtr material = mk<Metal>(Color(0.7, 0.6, 0.5), 0.3);
+    world.add(mk<Triangle>(point1, point2, point3, material));
+    world.add(mk<Triangle>(point4, point2, point3, material));
+    const Color c1 = random_vec3(0.0, 1.0);
+    const Color c2 = random_vec3(0.0, 1.0);
+    world.add(mk<Sphere>(Point(0.0, 0.5, -3.0), 0.5, MatPtr(mk<Lambertian>(elemul(c1, c2)))));
+    world.add(mk<Sphere>(Point(0.0, -1000.0, 0.0), 1000.0, checker_ground()));
+    return BVHNode::create(world, 0.0, 1.0);
+}
+
+static void kaleidoscope_objects(HittableList& world) {  // src/main.rs:741-763
+    MatPtr metal_material = mk<Metal>(Color(0.8, 0.8, 0.8), 0.01);
+    HitPtr edge = mk<Box6>(Point(0.0, 0.0, 0.0), Point(3.0, 20.0, 0.1), metal_material);
+    world.add(edge);
+    world.add(mk<Translate>(HitPtr(mk<RotateY>(edge, 60.0)), Vec3(0.0, 0.0, 0.0)));
+    world.add(mk<Translate>(HitPtr(mk<RotateY>(edge, 120.0)), Vec3(2.98, 0.0, 0.0)));
+    world.add(mk<Triangle>(Point(2.5, 22.0, -0.1), Point(1.5, 20.0, -0.86), Point(1.9, 20.0, -1.5),
+                           MatPtr(mk<Lambertian>(Color(1.0, 0.45, 0.45)))));
+}
+
+static HitPtr kaleidoscope() {  // src/main.rs:740-765
+    HittableList world;
+    kaleidoscope_objects(world);
+    return BVHNode::create(world, 0.0, 1.0);
+}
+
+// Scene 12, build-defined (the reference has no large mesh): the kaleidoscope plus a soup of
+// jittered Lambertian triangles in four layers behind the far end of the mirror tube.
+//   layers l = 0..3 at y = 20.5 + 0.5 l; G x G cells over x in [-8.5, 11.5], z in [-10.866, 9.134],
+//   G = ceil(sqrt(n / 8)); per cell the corners (a, b) = (0,0), (1,0), (0,1), (1,1) are jittered by
+//   0.2 cell in x and z and by 0.2 in y (draw order x, y, z); two triangles (p10, p01, p00) and
+//   (p01, p10, p11), each followed by its palette pick random_int(0, 63). The 64 palette colours are
+//   drawn first, Color::random(0.1, 0.95) each.
+static HitPtr kaleidoscope_mesh(const SceneOptions& o) {
+    HittableList world;
+    kaleidoscope_objects(world);
+    std::vector<MatPtr> palette;
+    for (int i = 0; i < 64; ++i) palette.push_back(mk<Lambertian>(random_vec3(0.1, 0.95)));
+    const int layers = 4;
+    uint64_t G = (uint64_t)std::ceil(std::sqrt((double)o.n_triangles / (2.0 * layers)));
+    if (G < 1) G = 1;
+    const double X0 = -8.5, Z0 = -10.866, W = 20.0;
+    const double h = W / (double)G;
+    world.objects.reserve(world.objects.size() + (size_t)(2 * layers * G * G));
+    for (int l = 0; l < layers; ++l) {
+        const double yl = 20.5 + 0.5 * (double)l;
+        for (uint64_t i = 0; i < G; ++i) {
+            for (uint64_t j = 0; j < G; ++j) {
+                Point c[2][2];
+                for (int b = 0; b < 2; ++b) {
+                    for (int a = 0; a < 2; ++a) {
+                        const double px = X0 + ((double)i + (double)a) * h + 0.2 * h * random_double(-1.0, 1.0);
+                        const double py = yl + 0.2 * random_double(-1.0, 1.0);
+                        const double pz = Z0 + ((double)j + (double)b) * h + 0.2 * h * random_double(-1.0, 1.0);
+                        c[a][b] = Point(px, py, pz);
+                    }
+                }
+                MatPtr m1 = palette[(size_t)random_int(0, 63)];
+                world.add(mk<Triangle>(c[1][0], c[0][1], c[0][0], m1));
+                MatPtr m2 = palette[(size_t)random_int(0, 63)];
+                world.add(mk<Triangle>(c[0][1], c[1][0], c[1][1], m2));
+            }
+        }
+    }
+    return BVHNode::create(world, 0.0, 1.0);
+}
+
+HitPtr build_scene(int scene, const SceneOptions& o) {
+    switch (scene) {
+        case RT_SCENE_RANDOM: case RT_SCENE_RANDOM_PINHOLE: return random_scene(o);
+        case RT_SCENE_SIMPLE_LIGHT: return simple_light();
+        case RT_SCENE_LIGHT_DEMO: return light_demo();
+        case RT_SCENE_TWO_PERLIN: return two_perlin_spheres();
+        case RT_SCENE_EARTH: return earth(o);
+        case RT_SCENE_CORNELL: return cornell_box();
+        case RT_SCENE_CORNELL_SMOKE: return cornell_smoke();
+        case RT_SCENE_FINAL: return final_scene(o);
+        case RT_SCENE_TRIANGLE: return try_triangle();
+        case RT_SCENE_KALEIDOSCOPE: return kaleidoscope();
+        case RT_SCENE_KALEIDOSCOPE_MESH: return kaleidoscope_mesh(o);
+    }
+    return nullptr;
+}
+
+}  // namespace rth

@@ -1,0 +1,468 @@
+// Implementation of the device-facing entry points of include/rt/abi.h: scene
+// upload, closest-hit queries, the wavefront render loop and resolve.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt/abi.h"
+#include "device/kernels.h"
+#include "host/errors.hpp"
+
+namespace {
+
+using rtd::DevScene;
+using rtd::PathState;
+using rtd::RenderConst;
+
+constexpr uint64_t kDefaultSlotTarget = 16u << 20;  // path slots per wavefront batch when the caller does not say
+constexpr int kWorkWords = 10;                      // entries + 9 kinds
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return rt::set_error(e_ == hipErrorOutOfMemory ? RT_E_NOMEM : RT_E_DEVICE,                     \
+                                 std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+struct Workspace {
+    uint64_t cap_slots = 0;
+    char* base = nullptr;  // one allocation: 14 f64 columns, hit_ref, hit_aux, two queues
+    PathState P{};
+    uint32_t* queue[2] = {nullptr, nullptr};
+    uint32_t* counts = nullptr;              // [2] queue lengths
+    unsigned long long* ray_total = nullptr; // [1] + work counters [kWorkWords]
+    std::vector<hipEvent_t> events;
+};
+
+}  // namespace
+
+struct RtScene {
+    int device = 0;
+    DevScene S{};
+    std::vector<void*> allocs;
+    Workspace ws;
+    uint32_t n_cus = 256;
+};
+
+namespace {
+
+// ---- validation: nothing a kernel indexes with may point outside its table ------------------
+int validate(const RtSceneDesc* d) {
+    auto bad = [](const char* what) { return rt::set_error(RT_E_INVALID, std::string("scene description: ") + what); };
+    if (!d) return bad("null");
+    if (d->abi_version != RT_ABI_VERSION) return bad("abi_version mismatch");
+    if (d->n_nodes >= 0xFFFFFFFFull) return bad("too many entries");
+    const uint64_t counts[] = {d->n_nodes, d->n_spheres, d->n_msphere, d->n_rects, d->n_boxes, d->n_triangles, d->n_xforms,
+                               d->n_media, d->n_materials, d->n_textures, d->n_perlins, d->n_images, d->n_texel_bytes};
+    const void* ptrs[] = {d->nodes, d->spheres, d->msphere, d->rects, d->boxes, d->triangles, d->xforms,
+                          d->media, d->materials, d->textures, d->perlins, d->images, d->texels};
+    for (int i = 0; i < 13; ++i)
+        if (counts[i] && !ptrs[i]) return bad("non-zero count with a null table");
+    for (uint64_t i = 0; i < d->n_images; ++i) {
+        const RtImage& im = d->images[i];
+        if (im.width == 0 || im.height == 0) return bad("empty image");
+        if (im.offset > d->n_texel_bytes || (uint64_t)im.width * im.height * 3u > d->n_texel_bytes - im.offset) return bad("image outside texel blob");
+    }
+    for (uint64_t i = 0; i < d->n_textures; ++i) {
+        const RtTexture& t = d->textures[i];
+        if (t.kind > RT_T_IMAGE) return bad("texture kind");
+        if (t.kind == RT_T_NOISE && t.aux >= d->n_perlins) return bad("texture -> perlin index");
+        if (t.kind == RT_T_IMAGE && t.aux >= d->n_images) return bad("texture -> image index");
+    }
+    for (uint64_t i = 0; i < d->n_perlins; ++i)
+        for (int k = 0; k < 256; ++k) {
+            const RtPerlin& p = d->perlins[i];
+            if ((uint32_t)p.perm_x[k] > 255u || (uint32_t)p.perm_y[k] > 255u || (uint32_t)p.perm_z[k] > 255u) return bad("perlin permutation entry");
+        }
+    for (uint64_t i = 0; i < d->n_materials; ++i) {
+        const RtMaterial& m = d->materials[i];
+        if (m.kind > RT_M_ISOTROPIC) return bad("material kind");
+        const bool textured = m.kind == RT_M_LAMBERTIAN || m.kind == RT_M_DIFFUSE_LIGHT || m.kind == RT_M_ISOTROPIC;
+        if (textured && m.tex >= d->n_textures) return bad("material -> texture index");
+    }
+    auto mat_ok = [&](uint32_t m) { return m < d->n_materials; };
+    for (uint64_t i = 0; i < d->n_spheres; ++i) if (!mat_ok(d->spheres[i].mat)) return bad("sphere material");
+    for (uint64_t i = 0; i < d->n_msphere; ++i) if (!mat_ok(d->msphere[i].mat)) return bad("moving sphere material");
+    for (uint64_t i = 0; i < d->n_rects; ++i) if (!mat_ok(d->rects[i].mat) || d->rects[i].axis > 2u) return bad("rect material/axis");
+    for (uint64_t i = 0; i < d->n_boxes; ++i) if (!mat_ok(d->boxes[i].mat)) return bad("box material");
+    for (uint64_t i = 0; i < d->n_triangles; ++i) if (!mat_ok(d->triangles[i].mat)) return bad("triangle material");
+    for (uint64_t i = 0; i < d->n_media; ++i) if (!mat_ok(d->media[i].mat) || d->media[i].rng_id >= 0xFFF0u) return bad("medium material/rng id");
+    for (uint64_t i = 0; i < d->n_xforms; ++i) {
+        const RtXform& x = d->xforms[i];
+        if (x.kind > 1u || x.depth < 1u || x.depth > 4u) return bad("xform kind/depth");
+        for (uint32_t k = 0; k < x.depth; ++k) if (x.anc[k] >= d->n_xforms) return bad("xform ancestor index");
+        if (x.anc[x.depth - 1u] != i) return bad("xform ancestor chain does not end at itself");
+        for (uint32_t k = 0; k + 1u < x.depth; ++k) if (d->xforms[x.anc[k]].depth != k + 1u) return bad("xform ancestor depth");
+    }
+    // entry stream: links forward and inside the stream, indices inside their tables, wrappers balanced
+    const uint64_t table_n[9] = {0, d->n_spheres, d->n_msphere, d->n_rects, d->n_boxes, d->n_triangles, d->n_xforms, d->n_xforms, d->n_media};
+    std::vector<uint32_t> open;        // xform stack
+    uint64_t medium_end = 0;           // end of the boundary range we are inside (0 = none)
+    for (uint64_t i = 0; i < d->n_nodes; ++i) {
+        const RtNode& n = d->nodes[i];
+        const uint32_t kind = n.meta & 15u, idx = n.meta >> 4;
+        if (kind > RT_N_MEDIUM) return bad("entry kind");
+        if (kind != RT_N_INNER && idx >= table_n[kind]) return bad("entry -> table index");
+        if (medium_end && i >= medium_end) medium_end = 0;
+        if (kind == RT_N_INNER || kind == RT_N_MEDIUM) {
+            if (n.link <= i || n.link > d->n_nodes) return bad("entry link");
+            if (medium_end && n.link > medium_end) return bad("entry link leaves the medium boundary");
+        }
+        if (kind == RT_N_MEDIUM) {
+            if (medium_end) return bad("medium inside a medium boundary");
+            medium_end = n.link;
+        }
+        if (kind == RT_N_XF_ENTER) {
+            const RtXform& x = d->xforms[idx];
+            if (x.depth != open.size() + 1u) return bad("wrapper depth does not match nesting");
+            for (size_t k = 0; k < open.size(); ++k) if (x.anc[k] != open[k]) return bad("wrapper ancestors do not match nesting");
+            open.push_back(idx);
+        } else if (kind == RT_N_XF_EXIT) {
+            if (open.empty() || open.back() != idx) return bad("unbalanced wrapper exit");
+            open.pop_back();
+        }
+    }
+    if (!open.empty()) return bad("unbalanced wrapper enter");
+    return RT_OK;
+}
+
+template <class T>
+int upload(RtScene* s, const T* src, uint64_t n, const T** dst) {
+    *dst = nullptr;
+    if (n == 0) return RT_OK;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+    s->allocs.push_back(p);
+    HIP_TRY(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T*>(p);
+    return RT_OK;
+}
+
+int bind_device(RtScene* s) {
+    HIP_TRY(hipSetDevice(s->device));
+    return RT_OK;
+}
+
+uint32_t grid_for(const RtScene* s, uint64_t n) {
+    const uint64_t want = (n + rtd::BLOCK - 1) / rtd::BLOCK;
+    const uint64_t cap = (uint64_t)s->n_cus * 8u;  // 8 blocks of 256 threads fill a CU's 32 wave slots
+    return (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
+}
+
+void free_workspace(Workspace& w) {
+    if (w.base) (void)hipFree(w.base);
+    if (w.counts) (void)hipFree(w.counts);
+    if (w.ray_total) (void)hipFree(w.ray_total);
+    for (auto e : w.events) (void)hipEventDestroy(e);
+    w = Workspace();
+}
+
+int ensure_workspace(RtScene* s, uint64_t n_slots) {
+    Workspace& w = s->ws;
+    if (!w.counts) {
+        HIP_TRY(hipMalloc((void**)&w.counts, 2 * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&w.ray_total, (1 + kWorkWords) * sizeof(unsigned long long)));
+    }
+    if (w.cap_slots >= n_slots) return RT_OK;
+    if (w.base) { HIP_TRY(hipFree(w.base)); w.base = nullptr; w.cap_slots = 0; }
+    const uint64_t bytes = n_slots * (14 * sizeof(double) + 4 * sizeof(uint32_t));
+    HIP_TRY(hipMalloc((void**)&w.base, bytes));
+    double* dcol = reinterpret_cast<double*>(w.base);
+    double** cols[14] = {&w.P.ox, &w.P.oy, &w.P.oz, &w.P.dx, &w.P.dy, &w.P.dz, &w.P.tm, &w.P.tr, &w.P.tg, &w.P.tb,
+                         &w.P.lr, &w.P.lg, &w.P.lb, &w.P.hit_t};
+    for (int i = 0; i < 14; ++i) *cols[i] = dcol + (uint64_t)i * n_slots;
+    uint32_t* ucol = reinterpret_cast<uint32_t*>(dcol + 14 * n_slots);
+    w.P.hit_ref = ucol;
+    w.P.hit_aux = ucol + n_slots;
+    w.queue[0] = ucol + 2 * n_slots;
+    w.queue[1] = ucol + 3 * n_slots;
+    w.cap_slots = n_slots;
+    return RT_OK;
+}
+
+int check_render_args(const RtScene* s, const RtCamera* cam, const RtRenderParams* p, const float* accum) {
+    if (!s || !cam || !p || !accum) return rt::set_error(RT_E_INVALID, "null argument");
+    if (p->width < 2 || p->height < 2) return rt::set_error(RT_E_INVALID, "width and height must be at least 2");
+    if ((uint64_t)p->width * p->height >= (1ull << 31)) return rt::set_error(RT_E_INVALID, "image too large");
+    if (p->sample_end < p->sample_begin) return rt::set_error(RT_E_INVALID, "sample_end < sample_begin");
+    if (p->max_depth > 0xFFFFu) return rt::set_error(RT_E_INVALID, "max_depth too large");
+    return RT_OK;
+}
+
+int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* accum_dev, hipStream_t stream,
+                     RtRenderStats* stats) {
+    if (int rc = bind_device(s)) return rc;
+    const uint64_t npix = (uint64_t)p->width * p->height;
+    const uint32_t total = p->sample_end - p->sample_begin;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (total == 0) return RT_OK;
+    uint32_t spb = p->samples_per_batch;
+    if (spb == 0) spb = (uint32_t)std::max<uint64_t>(1, kDefaultSlotTarget / npix);
+    spb = std::min(spb, total);
+    if (npix * spb >= (1ull << 32)) spb = (uint32_t)(((1ull << 32) - 1) / npix);
+    if (int rc = ensure_workspace(s, npix * spb)) return rc;
+    Workspace& w = s->ws;
+
+    RenderConst C{};
+    C.cam = *cam;
+    C.seed = p->seed;
+    for (int k = 0; k < 3; ++k) C.bg[k] = p->background[k];
+    C.width = p->width; C.height = p->height; C.npix = (uint32_t)npix;
+    C.max_depth = p->max_depth;
+
+    const uint32_t n_batches = (total + spb - 1) / spb;
+    size_t ev_needed = stats ? 2 + (size_t)n_batches * p->max_depth * 4 : 0;
+    while (w.events.size() < ev_needed) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        w.events.push_back(e);
+    }
+    size_t ev = 0;
+    HIP_TRY(hipMemsetAsync(w.ray_total, 0, sizeof(unsigned long long), stream));
+    if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
+    for (uint32_t b = 0; b < n_batches; ++b) {
+        const uint32_t s0 = p->sample_begin + b * spb;
+        const uint32_t ns = std::min(spb, p->sample_end - s0);
+        C.sample0 = s0;
+        C.n_slots = (uint32_t)(npix * ns);
+        const uint32_t grid = grid_for(s, C.n_slots);
+        hipLaunchKernelGGL(rtd::k_generate, dim3(grid), dim3(rtd::BLOCK), 0, stream, C, w.P);
+        for (uint32_t bounce = 0; bounce < p->max_depth; ++bounce) {
+            const int cur = (int)(bounce & 1u), nxt = cur ^ 1;
+            const uint32_t* q = bounce == 0 ? nullptr : w.queue[cur];
+            HIP_TRY(hipMemsetAsync(w.counts + nxt, 0, sizeof(uint32_t), stream));
+            if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
+            hipLaunchKernelGGL(rtd::k_extend<false>, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts + cur, bounce,
+                               (unsigned long long*)nullptr);
+            if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
+            hipLaunchKernelGGL(rtd::k_shade, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts + cur, w.queue[nxt],
+                               w.counts + nxt, bounce, w.ray_total);
+            if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
+        }
+        hipLaunchKernelGGL(rtd::k_accumulate, dim3(grid_for(s, npix)), dim3(rtd::BLOCK), 0, stream, C, w.P, accum_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        HIP_TRY(hipEventRecord(w.events[ev++], stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, w.events[0], w.events[ev - 1]));
+        stats->ms_total = ms;
+        size_t k = 1;
+        for (uint32_t b = 0; b < n_batches; ++b)
+            for (uint32_t bounce = 0; bounce < p->max_depth; ++bounce) {
+                HIP_TRY(hipEventElapsedTime(&ms, w.events[k], w.events[k + 1])); stats->ms_extend += ms;
+                HIP_TRY(hipEventElapsedTime(&ms, w.events[k + 1], w.events[k + 2])); stats->ms_shade += ms;
+                k += 3;
+            }
+        unsigned long long rays = 0;
+        HIP_TRY(hipMemcpy(&rays, w.ray_total, sizeof rays, hipMemcpyDeviceToHost));
+        stats->rays = rays;
+        stats->paths = npix * total;
+        stats->batches = n_batches;
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
+    if (!out) return rt::set_error(RT_E_INVALID, "null output");
+    *out = nullptr;
+    if (int rc = validate(d)) return rc;
+    RtScene* s = new (std::nothrow) RtScene();
+    if (!s) return rt::set_error(RT_E_NOMEM, "out of host memory");
+    int rc = RT_OK;
+    do {
+        if (hipGetDevice(&s->device) != hipSuccess) { rc = rt::set_error(RT_E_DEVICE, "no HIP device"); break; }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) { rc = rt::set_error(RT_E_DEVICE, "hipGetDeviceProperties failed"); break; }
+        s->n_cus = (uint32_t)std::max(1, prop.multiProcessorCount);
+        if ((rc = upload(s, d->nodes, d->n_nodes, &s->S.nodes))) break;
+        if ((rc = upload(s, d->spheres, d->n_spheres, &s->S.spheres))) break;
+        if ((rc = upload(s, d->msphere, d->n_msphere, &s->S.msphere))) break;
+        if ((rc = upload(s, d->rects, d->n_rects, &s->S.rects))) break;
+        if ((rc = upload(s, d->boxes, d->n_boxes, &s->S.boxes))) break;
+        if ((rc = upload(s, d->triangles, d->n_triangles, &s->S.triangles))) break;
+        if ((rc = upload(s, d->xforms, d->n_xforms, &s->S.xforms))) break;
+        if ((rc = upload(s, d->media, d->n_media, &s->S.media))) break;
+        if ((rc = upload(s, d->materials, d->n_materials, &s->S.materials))) break;
+        if ((rc = upload(s, d->textures, d->n_textures, &s->S.textures))) break;
+        if ((rc = upload(s, d->perlins, d->n_perlins, &s->S.perlins))) break;
+        if ((rc = upload(s, d->images, d->n_images, &s->S.images))) break;
+        if ((rc = upload(s, d->texels, d->n_texel_bytes, &s->S.texels))) break;
+        s->S.n_nodes = (uint32_t)d->n_nodes;
+    } while (0);
+    if (rc) { rt_scene_destroy(s); return rc; }
+    *out = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(RtScene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    for (void* p : s->allocs) (void)hipFree(p);
+    free_workspace(s->ws);
+    delete s;
+}
+
+int rt_trace_closest_device(RtScene* s, const RtRay* rays_dev, uint64_t n, uint64_t seed, RtHit* out_dev, void* stream) {
+    if (!s || (n && (!rays_dev || !out_dev))) return rt::set_error(RT_E_INVALID, "null argument");
+    if (n == 0) return RT_OK;
+    if (int rc = bind_device(s)) return rc;
+    hipLaunchKernelGGL((rtd::k_trace<false, false>), dim3(grid_for(s, n)), dim3(rtd::BLOCK), 0, (hipStream_t)stream, s->S, rays_dev, n,
+                       seed, out_dev, (RtHitRecord*)nullptr, (unsigned long long*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Shared body of rt_trace_closest / rt_trace_records / rt_trace_work: host buffers in and out.
+int trace_host(RtScene* s, const RtRay* rays, uint64_t n, uint64_t seed, RtHit* hits, RtHitRecord* recs, uint64_t* work,
+               RtTraceStats* stats) {
+    if (!s || (n && !rays) || (n && !hits && !recs)) return rt::set_error(RT_E_INVALID, "null argument");
+    if (stats) stats->ms_kernel = 0.0;
+    if (work) std::memset(work, 0, kWorkWords * sizeof(uint64_t));
+    if (n == 0) return RT_OK;
+    if (int rc = bind_device(s)) return rc;
+    RtRay* d_rays = nullptr;
+    void* d_out = nullptr;
+    unsigned long long* d_work = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const size_t out_bytes = n * (recs ? sizeof(RtHitRecord) : sizeof(RtHit));
+    int rc = RT_OK;
+    auto cleanup = [&]() {
+        if (d_rays) (void)hipFree(d_rays);
+        if (d_out) (void)hipFree(d_out);
+        if (d_work) (void)hipFree(d_work);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc((void**)&d_rays, n * sizeof(RtRay)));
+        HIP_TRY(hipMalloc(&d_out, out_bytes));
+        HIP_TRY(hipMemcpy(d_rays, rays, n * sizeof(RtRay), hipMemcpyHostToDevice));
+        if (work) {
+            HIP_TRY(hipMalloc((void**)&d_work, kWorkWords * sizeof(unsigned long long)));
+            HIP_TRY(hipMemset(d_work, 0, kWorkWords * sizeof(unsigned long long)));
+        }
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        const dim3 grid(grid_for(s, n)), block(rtd::BLOCK);
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        if (recs) {
+            if (work) hipLaunchKernelGGL((rtd::k_trace<true, true>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)nullptr, (RtHitRecord*)d_out, d_work);
+            else hipLaunchKernelGGL((rtd::k_trace<true, false>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)nullptr, (RtHitRecord*)d_out, d_work);
+        } else {
+            if (work) hipLaunchKernelGGL((rtd::k_trace<false, true>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)d_out, (RtHitRecord*)nullptr, d_work);
+            else hipLaunchKernelGGL((rtd::k_trace<false, false>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)d_out, (RtHitRecord*)nullptr, d_work);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (stats) stats->ms_kernel = ms;
+        HIP_TRY(hipMemcpy(recs ? (void*)recs : (void*)hits, d_out, out_bytes, hipMemcpyDeviceToHost));
+        if (work) {
+            unsigned long long tmp[kWorkWords];
+            HIP_TRY(hipMemcpy(tmp, d_work, sizeof tmp, hipMemcpyDeviceToHost));
+            for (int k = 0; k < kWorkWords; ++k) work[k] = tmp[k];
+        }
+        return RT_OK;
+    };
+    rc = body();
+    cleanup();
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_trace_closest(RtScene* s, const RtRay* rays, uint64_t n, uint64_t seed, RtHit* out, RtTraceStats* stats) {
+    return trace_host(s, rays, n, seed, out, nullptr, nullptr, stats);
+}
+
+int rt_trace_records(RtScene* s, const RtRay* rays, uint64_t n, uint64_t seed, RtHitRecord* out) {
+    return trace_host(s, rays, n, seed, nullptr, out, nullptr, nullptr);
+}
+
+int rt_trace_work(RtScene* s, const RtRay* rays, uint64_t n, uint64_t seed, RtHit* out, uint64_t* work) {
+    if (!work) return rt::set_error(RT_E_INVALID, "null argument");
+    return trace_host(s, rays, n, seed, out, nullptr, work, nullptr);
+}
+
+int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* accum_dev, void* stream, RtRenderStats* stats) {
+    if (int rc = check_render_args(s, cam, p, accum_dev)) return rc;
+    return render_on_stream(s, cam, p, accum_dev, (hipStream_t)stream, stats);
+}
+
+int rt_render(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* accum_rgb, RtRenderStats* stats) {
+    if (int rc = check_render_args(s, cam, p, accum_rgb)) return rc;
+    if (int rc = bind_device(s)) return rc;
+    const size_t bytes = (size_t)p->width * p->height * 3 * sizeof(float);
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, bytes));
+    int rc = RT_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMemcpy(d, accum_rgb, bytes, hipMemcpyHostToDevice));
+        if (int r = render_on_stream(s, cam, p, d, nullptr, stats)) return r;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(accum_rgb, d, bytes, hipMemcpyDeviceToHost));
+        return RT_OK;
+    };
+    rc = body();
+    (void)hipFree(d);
+    return rc;
+}
+
+int rt_resolve_u8_device(const float* accum_dev, uint32_t width, uint32_t height, uint64_t spp, uint8_t* out_dev, void* stream) {
+    if (!accum_dev || !out_dev || spp == 0) return rt::set_error(RT_E_INVALID, "null argument or spp == 0");
+    const uint64_t n = (uint64_t)width * height * 3u;
+    if (n == 0) return RT_OK;
+    const double scale = 1.0 / (double)spp;  // src/main.rs:216
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + rtd::BLOCK - 1) / rtd::BLOCK, 2048);
+    hipLaunchKernelGGL(rtd::k_resolve, dim3(grid), dim3(rtd::BLOCK), 0, (hipStream_t)stream, accum_dev, n, scale, out_dev);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_resolve_u8(const float* accum_rgb, uint32_t width, uint32_t height, uint64_t spp, uint8_t* rgb_out) {
+    if (!accum_rgb || !rgb_out || spp == 0) return rt::set_error(RT_E_INVALID, "null argument or spp == 0");
+    const size_t n = (size_t)width * height * 3u;
+    if (n == 0) return RT_OK;
+    float* d_in = nullptr;
+    uint8_t* d_out = nullptr;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc((void**)&d_in, n * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&d_out, n));
+        HIP_TRY(hipMemcpy(d_in, accum_rgb, n * sizeof(float), hipMemcpyHostToDevice));
+        if (int r = rt_resolve_u8_device(d_in, width, height, spp, d_out, nullptr)) return r;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(rgb_out, d_out, n, hipMemcpyDeviceToHost));
+        return RT_OK;
+    };
+    const int rc = body();
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+}  // extern "C"

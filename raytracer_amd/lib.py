@@ -1,0 +1,193 @@
+"""ctypes binding of raytracer_amd/librt_hip.so (include/rt/abi.h, include/rt/host.h).
+
+There is no CPU fallback: if the shared library is missing, or no GPU is present
+when a device call is made, the call raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .hostapi import SceneApi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+
+ABI_SYMBOLS = (
+    "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_trace_closest",
+    "rt_trace_records", "rt_trace_closest_device", "rt_trace_work", "rt_render", "rt_render_device", "rt_resolve_u8",
+    "rt_resolve_u8_device",
+)
+HOST_SYMBOLS = (
+    "rth_scene_build", "rth_scene_desc", "rth_scene_setup", "rth_scene_free", "rth_camera_new", "rth_builder_new",
+    "rth_builder_free", "rth_tex_solid", "rth_tex_checker", "rth_tex_noise", "rth_tex_image", "rth_mat_lambertian",
+    "rth_mat_metal", "rth_mat_dielectric", "rth_mat_diffuse_light", "rth_mat_isotropic", "rth_sphere",
+    "rth_moving_sphere", "rth_xy_rect", "rth_xz_rect", "rth_yz_rect", "rth_box6", "rth_triangle", "rth_translate",
+    "rth_rotate_y", "rth_constant_medium", "rth_list_new", "rth_list_add", "rth_bvh", "rth_builder_finish",
+)
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class Library:
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise RtError("%s is missing: build it with `make -C raytracer_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no fallback path" % path)
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_abi_version.restype = C.c_uint32
+        self.host = SceneApi(L, "rth_", L.rt_last_error)
+        vp, u32, u64, i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+        P = C.POINTER
+        L.rth_scene_desc.argtypes = [vp]
+        L.rth_scene_desc.restype = P(abi.RtSceneDesc)
+        L.rt_device_count.restype = i
+        L.rt_scene_create.argtypes = [P(abi.RtSceneDesc), P(vp)]
+        L.rt_scene_destroy.argtypes = [vp]
+        L.rt_scene_destroy.restype = None
+        L.rt_trace_closest.argtypes = [vp, vp, u64, u64, vp, P(abi.RtTraceStats)]
+        L.rt_trace_records.argtypes = [vp, vp, u64, u64, vp]
+        L.rt_trace_closest_device.argtypes = [vp, vp, u64, u64, vp, vp]
+        L.rt_trace_work.argtypes = [vp, vp, u64, u64, vp, P(u64)]
+        L.rt_render.argtypes = [vp, P(abi.RtCamera), P(abi.RtRenderParams), vp, P(abi.RtRenderStats)]
+        L.rt_render_device.argtypes = [vp, P(abi.RtCamera), P(abi.RtRenderParams), vp, vp, P(abi.RtRenderStats)]
+        L.rt_resolve_u8.argtypes = [vp, u32, u32, u64, vp]
+        L.rt_resolve_u8_device.argtypes = [vp, u32, u32, u64, vp, vp]
+        for name in ABI_SYMBOLS:
+            f = getattr(L, name)
+            if name not in ("rt_last_error", "rt_abi_version", "rt_scene_destroy"):
+                f.restype = i
+        if L.rt_abi_version() != abi.RT_ABI_VERSION:
+            raise RtError("ABI version mismatch between librt_hip.so and raytracer_amd/abi.py")
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.lib.rt_last_error()
+            raise RtError("librt_hip call failed (%d): %s" % (rc, msg.decode() if msg else ""))
+
+    def device_count(self):
+        return self.lib.rt_device_count()
+
+
+_LIB = None
+
+
+def get():
+    global _LIB
+    if _LIB is None:
+        _LIB = Library()
+    return _LIB
+
+
+class HostScene:
+    """A flattened scene on the host (RtHostScene) — tables readable as numpy arrays."""
+
+    def __init__(self, lib, handle):
+        self.lib = lib
+        self.h = handle
+        self.desc = lib.lib.rth_scene_desc(handle).contents
+
+    @classmethod
+    def build(cls, scene_id, lib=None, **kw):
+        lib = lib or get()
+        return cls(lib, lib.host.scene_build(scene_id, **kw))
+
+    def table(self, name):
+        """Copy of one table of the description as a ctypes-backed numpy structured array."""
+        counts = {"nodes": "n_nodes", "spheres": "n_spheres", "msphere": "n_msphere", "rects": "n_rects", "boxes": "n_boxes",
+                  "triangles": "n_triangles", "xforms": "n_xforms", "media": "n_media", "materials": "n_materials",
+                  "textures": "n_textures", "perlins": "n_perlins", "images": "n_images"}
+        n = getattr(self.desc, counts[name])
+        ptr = getattr(self.desc, name)
+        if n == 0:
+            return []
+        typ = ptr._type_
+        arr = (typ * n).from_address(C.addressof(ptr.contents))
+        return np.frombuffer(bytes(arr), dtype=np.dtype(typ))
+
+    def close(self):
+        if self.h:
+            self.lib.host.scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceScene:
+    """An RtScene resident in the HBM of the current HIP device."""
+
+    def __init__(self, host_scene, lib=None):
+        self.lib = lib or host_scene.lib
+        self.h = C.c_void_p()
+        self.lib.check(self.lib.lib.rt_scene_create(C.byref(host_scene.desc), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib.lib.rt_scene_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def trace(self, rays, seed=0x5EED):
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY_DTYPE)
+        hits = np.zeros(rays.shape[0], dtype=abi.HIT_DTYPE)
+        st = abi.RtTraceStats()
+        self.lib.check(self.lib.lib.rt_trace_closest(self.h, rays.ctypes.data, rays.shape[0], seed, hits.ctypes.data, C.byref(st)))
+        return hits, st.ms_kernel
+
+    def trace_records(self, rays, seed=0x5EED):
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY_DTYPE)
+        recs = np.zeros(rays.shape[0], dtype=abi.HITREC_DTYPE)
+        self.lib.check(self.lib.lib.rt_trace_records(self.h, rays.ctypes.data, rays.shape[0], seed, recs.ctypes.data))
+        return recs
+
+    def trace_work(self, rays, seed=0x5EED):
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY_DTYPE)
+        hits = np.zeros(rays.shape[0], dtype=abi.HIT_DTYPE)
+        work = (C.c_uint64 * 10)()
+        self.lib.check(self.lib.lib.rt_trace_work(self.h, rays.ctypes.data, rays.shape[0], seed, hits.ctypes.data, work))
+        w = list(work)
+        return hits, {"entries": w[0], **{abi.NODE_KINDS[k]: w[1 + k] for k in range(9)}}
+
+    def render(self, cam, params, accum=None, want_stats=True):
+        """rt_render into a host float32 [H, W, 3] buffer (created zeroed if not given)."""
+        if accum is None:
+            accum = np.zeros((params.height, params.width, 3), dtype=np.float32)
+        assert accum.dtype == np.float32 and accum.flags["C_CONTIGUOUS"]
+        st = abi.RtRenderStats()
+        self.lib.check(self.lib.lib.rt_render(self.h, C.byref(cam), C.byref(params), accum.ctypes.data,
+                                             C.byref(st) if want_stats else None))
+        return accum, st
+
+    def render_device(self, cam, params, accum_ptr, stream=None, stats=None):
+        """rt_render_device: accum_ptr is a device address (int), stream a hipStream_t handle (int) or None."""
+        self.lib.check(self.lib.lib.rt_render_device(self.h, C.byref(cam), C.byref(params), C.c_void_p(accum_ptr),
+                                                    C.c_void_p(stream or 0), C.byref(stats) if stats is not None else None))
+
+
+def make_params(width, height, s0, s1, background, seed=0x5EED, max_depth=50, samples_per_batch=0):
+    p = abi.RtRenderParams()
+    p.width, p.height, p.sample_begin, p.sample_end = width, height, s0, s1
+    p.max_depth, p.samples_per_batch, p.seed = max_depth, samples_per_batch, seed
+    p.background = abi.vec3(background)
+    return p
+
+
+def resolve_u8(accum, spp, lib=None):
+    lib = lib or get()
+    a = np.ascontiguousarray(accum, dtype=np.float32)
+    out = np.zeros(a.shape, dtype=np.uint8)
+    lib.check(lib.lib.rt_resolve_u8(a.ctypes.data, a.shape[1], a.shape[0], spp, out.ctypes.data))
+    return out
