@@ -1,0 +1,110 @@
+"""The C ABI: headers compile as plain C, struct layouts match the ctypes mirrors, the shared library
+loads without a GPU and exports every function the headers declare, and argument errors come back as
+codes with a message rather than crashes. No device work here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from raytracer_amd import abi, lib
+
+STRUCTS = ["RtNode", "RtSphere", "RtMovingSphere", "RtRect", "RtBox6", "RtTriangle", "RtXform", "RtMedium", "RtMaterial",
+           "RtTexture", "RtPerlin", "RtImage", "RtSceneDesc", "RtRay", "RtHit", "RtHitRecord", "RtCamera", "RtRenderParams",
+           "RtTraceStats", "RtRenderStats", "RtSceneOptions", "RtSceneSetup"]
+
+
+def declared_functions():
+    names = []
+    for h in ("abi.h", "host.h"):
+        text = open(os.path.join(ROOT, "include", "rt", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(rth?_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_headers_are_c_and_layouts_match():
+    prog = "#include <stdio.h>\n#include \"rt/host.h\"\nint main(void){\n"
+    for s in STRUCTS:
+        prog += "printf(\"%s %%zu\\n\", sizeof(%s));\n" % (s, s)
+    prog += "return 0;}\n"
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "sizes.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "sizes")
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    sizes = dict(line.split() for line in out.strip().splitlines())
+    for s in STRUCTS:
+        assert int(sizes[s]) == C.sizeof(getattr(abi, s)), s
+    assert int(sizes["RtNode"]) == 32 and int(sizes["RtHit"]) == 32 and int(sizes["RtTriangle"]) == 80
+
+
+def test_library_exports_every_declared_symbol(rtlib):
+    names = declared_functions()
+    assert set(names) == set(lib.ABI_SYMBOLS) | set(lib.HOST_SYMBOLS)
+    for n in names:
+        assert getattr(rtlib.lib, n) is not None
+    assert rtlib.lib.rt_abi_version() == abi.RT_ABI_VERSION
+
+
+def test_product_does_not_reference_the_oracle():
+    # the shipped path must not import, link or call anything under oracle/
+    for base, _, files in os.walk(os.path.join(ROOT, "raytracer_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip", "Makefile")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "import oracle" not in text and "liboracle" not in text and "oracle/" not in text, os.path.join(base, f)
+    out = subprocess.run(["ldd", lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+def test_scene_create_rejects_malformed_descriptions(rtlib):
+    hs = lib.HostScene.build(7)
+    good = hs.desc
+
+    def create(desc):
+        h = C.c_void_p()
+        rc = rtlib.lib.rt_scene_create(C.byref(desc), C.byref(h))
+        return rc, rtlib.lib.rt_last_error().decode()
+
+    def clone():
+        d = abi.RtSceneDesc()
+        C.memmove(C.byref(d), C.byref(good), C.sizeof(d))
+        return d
+
+    d = clone(); d.abi_version = 99
+    rc, msg = create(d)
+    assert rc == -1 and "abi_version" in msg
+    d = clone(); d.rects = None
+    rc, msg = create(d)
+    assert rc == -1 and "null table" in msg
+    # corrupt a link / an index in a private copy of the entry stream
+    nodes = (abi.RtNode * good.n_nodes)()
+    C.memmove(nodes, good.nodes, C.sizeof(nodes))
+    d = clone(); d.nodes = nodes
+    nodes[0].link = good.n_nodes + 5
+    rc, msg = create(d)
+    assert rc == -1 and "link" in msg
+    nodes[0].link = good.n_nodes
+    leaf = next(i for i in range(good.n_nodes) if (nodes[i].meta & 15) == 3)
+    nodes[leaf].meta = 3 | (1000 << 4)
+    rc, msg = create(d)
+    assert rc == -1 and "table index" in msg
+    rc = rtlib.lib.rt_scene_create(None, C.byref(C.c_void_p()))
+    assert rc == -1
+    hs.close()
+
+
+def test_null_arguments_return_codes(rtlib):
+    L = rtlib.lib
+    assert L.rt_trace_closest(None, None, 4, 0, None, None) == -1
+    assert L.rt_render(None, None, None, None, None) == -1
+    assert L.rt_resolve_u8(None, 4, 4, 1, None) == -1
+    assert L.rt_resolve_u8_device(None, 4, 4, 0, None, None) == -1
+    assert "null" in L.rt_last_error().decode()
+    L.rt_scene_destroy(None)  # no-op

@@ -1,0 +1,153 @@
+"""GPU parity of the render path (generate / extend / shade / accumulate / resolve through rt_render*):
+images against the CPU oracle within a self-calibrated RMSE, exactness properties that do not depend
+on image size, and the BASELINE configurations at full resolution through such properties."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import CONFIG_SCENES, SEED, scene_kwargs
+from raytracer_amd import abi, lib
+
+pytestmark = pytest.mark.gpu
+
+
+def setup_pair(gpu, orc, sid, seed=SEED):
+    kw = scene_kwargs(sid)
+    hs = lib.HostScene.build(sid, seed=seed, **kw)
+    ds = lib.DeviceScene(hs)
+    osc = orc.api.scene_build(sid, seed=seed, **kw)
+    su = gpu.host.scene_setup(sid)
+    cam = gpu.host.camera(su)
+    return hs, ds, osc, su, cam
+
+
+def resolved(acc, spp):
+    return np.sqrt(np.asarray(acc, dtype=np.float64) / spp)  # un-quantised display values, src/main.rs:216-219
+
+
+@pytest.mark.parametrize("sid", CONFIG_SCENES)
+def test_image_rmse_vs_oracle(gpu, orc, sid):
+    # Tolerance: RMSE(GPU, oracle) on resolved [0,1] values must stay below 1.5 x the RMSE between two oracle
+    # renders that differ only in the RNG seed (the noise floor at this sample count); in practice the GPU follows
+    # the oracle's paths and lands orders of magnitude below it.
+    hs, ds, osc, su, cam = setup_pair(gpu, orc, sid)
+    W = 72
+    H = int(W / su.aspect_ratio)
+    spp = 24
+    p = lib.make_params(W, H, 0, spp, list(su.background), seed=SEED)
+    acc_g, st = ds.render(cam, p)
+    acc_o, ost, _ = orc.render(osc, cam, p, mode=oracle.AABB_TIGHT, threads=8)
+    p2 = lib.make_params(W, H, 0, spp, list(su.background), seed=SEED + 1)
+    acc_o2, _, _ = orc.render(osc, cam, p2, mode=oracle.AABB_TIGHT, threads=8)
+    a, b, c = resolved(acc_o, spp), resolved(acc_g, spp), resolved(acc_o2, spp)
+    noise = float(np.sqrt(np.mean((a - c) ** 2)))
+    rmse = float(np.sqrt(np.mean((a - b) ** 2)))
+    assert noise > 0
+    assert rmse <= 1.5 * noise, (rmse, noise)
+    assert st.paths == W * H * spp
+    assert abs(int(st.rays) - ost["rays"]) <= 0.005 * ost["rays"], (st.rays, ost["rays"])
+    assert np.isfinite(acc_g).all() and (acc_g >= 0).all()
+    ds.close(); hs.close(); orc.api.scene_free(osc)
+
+
+def test_deterministic_and_partition_invariant(gpu, orc):
+    hs, ds, osc, su, cam = setup_pair(gpu, orc, 9)
+    W = H = 64
+    bg = list(su.background)
+    full, _ = ds.render(cam, lib.make_params(W, H, 0, 8, bg))
+    again, _ = ds.render(cam, lib.make_params(W, H, 0, 8, bg))
+    assert np.array_equal(full, again), "two identical renders must be bit-identical"
+    parts = np.zeros((H, W, 3), dtype=np.float32)
+    ds.render(cam, lib.make_params(W, H, 0, 3, bg), accum=parts)
+    ds.render(cam, lib.make_params(W, H, 3, 8, bg), accum=parts)
+    assert np.allclose(parts, full, rtol=2e-6, atol=1e-6)  # same samples, different f32 summation order
+    one_by_one, _ = ds.render(cam, lib.make_params(W, H, 0, 8, bg, samples_per_batch=1))
+    assert np.allclose(one_by_one, full, rtol=2e-6, atol=1e-6)
+    other_seed, _ = ds.render(cam, lib.make_params(W, H, 0, 8, bg, seed=SEED + 9))
+    assert not np.array_equal(other_seed, full)
+    empty, st = ds.render(cam, lib.make_params(W, H, 5, 5, bg))
+    assert not empty.any() and st.paths == 0
+    ds.close(); hs.close(); orc.api.scene_free(osc)
+
+
+def test_all_rays_miss_gives_background_exactly(gpu):
+    b = gpu.host.builder()
+    far = b.sphere([0, 0, 1000], 1.0, b.lambertian([0.5, 0.5, 0.5]))  # behind the camera
+    hs = lib.HostScene(gpu, b.finish(b.bvh(b.list([far]))))
+    ds = lib.DeviceScene(hs)
+    cam = gpu.host.camera_new([0, 0, 0], [0, 0, -1], [0, 1, 0], 40.0, 1.5, 0.1, 10.0)
+    bg = [0.52, 0.80, 0.92]
+    acc, st = ds.render(cam, lib.make_params(48, 32, 0, 5, bg))
+    expect = np.array([np.float32(5 * c) for c in bg])
+    assert (acc == expect).all()
+    assert st.rays == st.paths == 48 * 32 * 5
+    out = lib.resolve_u8(acc, 5)
+    assert (out == np.array([183, 228, 244], dtype=np.uint8)).all()  # src/main.rs:153 through :216-224
+    ds.close(); hs.close()
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 50])
+def test_depth_limit_matches_oracle(gpu, orc, depth):
+    # ray_color(depth) issues at most `depth` world.hit queries and returns black below that (src/color.rs:37-39)
+    hs, ds, osc, su, cam = setup_pair(gpu, orc, 7)
+    p = lib.make_params(40, 40, 0, 8, list(su.background), max_depth=depth)
+    acc_g, st = ds.render(cam, p)
+    acc_o, ost, _ = orc.render(osc, cam, p, mode=oracle.AABB_TIGHT, threads=4)
+    assert st.rays == ost["rays"]
+    assert np.allclose(acc_g, acc_o, rtol=1e-5, atol=1e-5)
+    ds.close(); hs.close(); orc.api.scene_free(osc)
+
+
+def test_resolve_matches_oracle_bit_for_bit(gpu, orc):
+    rng = np.random.default_rng(3)
+    acc = (rng.uniform(0, 40, (37, 53, 3)) * (rng.uniform(size=(37, 53, 3)) < 0.9)).astype(np.float32)
+    acc[0, 0] = [np.nan, -1.0, 1e30]
+    acc[0, 1] = [0.0, 16.0 * 0.999 ** 2, 16.0]
+    out = lib.resolve_u8(acc, 16)
+    ref = orc.resolve_u8(acc.astype(np.float64), 16)
+    assert np.array_equal(out, ref)
+    assert out[0, 0].tolist() == [0, 0, 254]
+
+
+def test_render_device_with_torch_buffers(gpu, orc):
+    import torch
+    hs, ds, osc, su, cam = setup_pair(gpu, orc, 8)
+    W = H = 48
+    p = lib.make_params(W, H, 0, 6, list(su.background))
+    host, _ = ds.render(cam, p)
+    accum = torch.zeros(H, W, 3, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.Stream()
+    st = abi.RtRenderStats()
+    with torch.cuda.stream(stream):
+        ds.render_device(cam, p, accum.data_ptr(), stream.cuda_stream, stats=st)
+    stream.synchronize()
+    assert np.array_equal(accum.cpu().numpy(), host)
+    u8 = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    gpu.check(gpu.lib.rt_resolve_u8_device(accum.data_ptr(), W, H, 6, u8.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(u8.cpu().numpy(), lib.resolve_u8(host, 6))
+    ds.close(); hs.close(); orc.api.scene_free(osc)
+
+
+FULL = {1: (1200, 800), 7: (600, 600), 8: (600, 600), 9: (800, 800)}
+
+
+@pytest.mark.parametrize("sid", sorted(FULL))
+def test_full_resolution_properties(gpu, orc, sid):
+    # BASELINE image sizes, few samples: additivity over sample ranges, exact repeatability, finite non-negative
+    # radiance, every path issues at least one query, and the image mean agrees with a low-resolution oracle render.
+    hs, ds, osc, su, cam = setup_pair(gpu, orc, sid)
+    W, H = FULL[sid]
+    bg = list(su.background)
+    a, sa = ds.render(cam, lib.make_params(W, H, 0, 2, bg))
+    b, sb = ds.render(cam, lib.make_params(W, H, 2, 4, bg))
+    both, sab = ds.render(cam, lib.make_params(W, H, 0, 4, bg))
+    assert np.allclose(a + b, both, rtol=2e-6, atol=1e-6)
+    assert sa.rays + sb.rays == sab.rays and sab.paths == W * H * 4 and sab.rays >= sab.paths
+    assert np.isfinite(both).all() and (both >= 0).all()
+    small = orc.render(osc, cam, lib.make_params(W // 10, H // 10, 0, 16, bg), mode=oracle.AABB_TIGHT, threads=8)[0]
+    m_gpu, m_orc = both.mean() / 4, small.mean() / 16
+    assert abs(m_gpu - m_orc) <= 0.12 * m_orc + 1e-3, (m_gpu, m_orc)
+    ds.close(); hs.close(); orc.api.scene_free(osc)

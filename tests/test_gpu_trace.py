@@ -1,0 +1,219 @@
+"""GPU parity of the closest-hit query (rt_trace_*): the HIP traversal against the committed golden
+vectors and against the CPU oracle on seeded ray sets. Bar: primitive ids, box sides and wrapper ids
+bit-exact; t within 4 ulp (0 ulp wherever no log10 is involved); the traversal itself must do exactly
+the oracle's work (same number of box tests and primitive tests)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import CONFIG_SCENES, SCENE_OPTS, SEED, load_golden, scene_kwargs, ulp_diff
+from raytracer_amd import abi, lib
+
+pytestmark = pytest.mark.gpu
+
+T_ULP = 4  # north-star tolerance on t
+
+
+def compare_hits(oh, gh, what=""):
+    assert np.array_equal(oh["prim_id"], gh["prim_id"]), what + ": primitive ids differ"
+    assert np.array_equal(oh["sub"], gh["sub"]), what + ": box side / wrapper ids differ"
+    hit = oh["prim_id"] != abi.RT_MISS
+    d = ulp_diff(oh["t"][hit], gh["t"][hit])
+    assert d.max(initial=0) <= T_ULP, what + ": t off by %d ulp" % d.max(initial=0)
+    # u, v go through atan2/asin on spheres (libm vs device math): a few ulp of values in [0, 1]
+    assert np.abs(oh["u"][hit] - gh["u"][hit]).max(initial=0) < 1e-14
+    assert np.abs(oh["v"][hit] - gh["v"][hit]).max(initial=0) < 1e-14
+    return d
+
+
+@pytest.mark.parametrize("sid", sorted(SCENE_OPTS))
+def test_golden_ray_set(gpu, sid):
+    g = load_golden(sid)
+    hs = lib.HostScene.build(sid, seed=SEED, **scene_kwargs(sid))
+    ds = lib.DeviceScene(hs)
+    hits, _ = ds.trace(g["rays"], seed=SEED)
+    d = compare_hits(g["hits"], hits, "scene %d" % sid)
+    recs = ds.trace_records(g["rays"], seed=SEED)
+    gr = g["records"]
+    hit = g["hits"]["prim_id"] != abi.RT_MISS
+    assert np.array_equal(recs["prim_id"], gr["prim_id"]) and np.array_equal(recs["sub"], gr["sub"])
+    assert np.array_equal(recs["front_face"], gr["front_face"])
+    exact = hit.copy()
+    exact[hit] = d == 0
+    # where t is bit-identical so are the point and the normal (only + - * / sqrt are involved)
+    assert np.array_equal(recs["p"][exact], gr["p"][exact])
+    assert np.array_equal(recs["normal"][exact], gr["normal"][exact])
+    rest = hit & ~exact  # ConstantMedium hits: t carries a log10
+    assert np.allclose(recs["p"][rest], gr["p"][rest], rtol=1e-13, atol=1e-11)
+    assert np.array_equal(recs["normal"][rest], gr["normal"][rest])
+    if sid not in (8, 9):
+        assert d.max(initial=0) == 0, "t must be bit-identical in scenes without media"
+    ds.close()
+    hs.close()
+
+
+@pytest.mark.parametrize("sid", CONFIG_SCENES)
+def test_seeded_ray_set_and_work_vs_oracle(gpu, orc, sid):
+    seed = 0xC0FFEE + sid
+    kw = scene_kwargs(sid)
+    hs = lib.HostScene.build(sid, seed=seed, **kw)
+    ds = lib.DeviceScene(hs)
+    osc = orc.api.scene_build(sid, seed=seed, **kw)
+    su = orc.api.scene_setup(sid)
+    cam = orc.api.camera(su)
+    W = 256
+    p = orc.make_params(W, int(W / su.aspect_ratio), 0, 4, list(su.background), seed=seed)
+    rays = orc.harvest(osc, cam, p, n_paths=40000, max_rays=1 << 16, max_bounce=3)
+    assert len(rays) > 30000
+    oh, _, ost = orc.trace(osc, rays, seed=seed, mode=oracle.AABB_TIGHT)
+    gh, work = ds.trace_work(rays, seed=seed)
+    compare_hits(oh, gh, "scene %d" % sid)
+    gh2, _ = ds.trace(rays, seed=seed)
+    assert np.array_equal(gh, gh2), "instrumented and plain kernels disagree"
+    # same traversal: same number of box tests and of primitive tests of every kind
+    assert work["inner"] == ost["box_tests"]
+    assert work["sphere"] == ost["sphere"] and work["msphere"] == ost["msphere"]
+    assert work["box6"] == ost["box6"] and work["triangle"] == ost["triangle"] and work["medium"] == ost["medium"]
+    assert work["rect"] == ost["rect"] - 6 * ost["box6"]  # the oracle counts the six sides of a box as rect tests
+    ds.close()
+    hs.close()
+    orc.api.scene_free(osc)
+
+
+def random_scene_pair(rng, rtlib, orc, n_obj):
+    """The same random ad-hoc scene in the product builder and the oracle builder."""
+    # identical call sequence and scene-stream seed (it picks the BVH split axes) on both
+    seed = int(rng.integers(1 << 30))
+    builders = [rtlib.host.builder(seed=seed), orc.api.builder(seed=seed)]
+    roots = []
+    plan = []
+    kinds = rng.integers(0, 9, size=n_obj)
+    for k in kinds:
+        c = rng.uniform(-4, 4, 3)
+        plan.append((int(k), c, rng.uniform(0.2, 1.2), rng.uniform(-1, 1, 3), rng.uniform(-60, 60), rng.uniform(0.05, 0.8),
+                     rng.uniform(0.3, 1.5, 3), int(rng.integers(0, 3))))
+    for b in builders:
+        m = [b.lambertian([0.5, 0.5, 0.5]), b.metal([0.8, 0.7, 0.6], 0.1), b.dielectric(1.5)]
+        objs = []
+        for (k, c, r, off, ang, dens, ext, mi) in plan:
+            mat = m[mi]
+            if k == 0:
+                o = b.sphere(c, r, mat)
+            elif k == 1:
+                o = b.moving_sphere(c, c + off * 0.3, 0.0, 1.0, r * 0.5, mat)
+            elif k == 2:
+                o = [b.xy_rect, b.xz_rect, b.yz_rect][mi](c[0], c[0] + ext[0], c[1], c[1] + ext[1], c[2], mat)
+            elif k == 3:
+                o = b.box6(c, c + ext, mat)
+            elif k == 4:
+                o = b.triangle(c + [ext[0], 0, 0.1], c + [0, ext[1], -0.2], c, mat)
+            elif k == 5:
+                o = b.translate(b.rotate_y(b.box6(c, c + ext, mat), ang), off)
+            elif k == 6:
+                o = b.constant_medium(b.sphere(c, r, mat), dens, [0.9, 0.9, 0.9])
+            elif k == 7:
+                o = b.constant_medium(b.translate(b.rotate_y(b.box6(c, c + ext, mat), ang), off), dens, [0.2, 0.4, 0.9])
+            else:  # a nested BVH of small spheres inside rotate(translate(rotate()))
+                inner = [b.sphere(c + rng_off, 0.15, mat) for rng_off in ([0, 0, 0], [0.4, 0, 0], [0, 0.4, 0], [0, 0, 0.4], [0.4, 0.4, 0])]
+                o = b.rotate_y(b.translate(b.rotate_y(b.bvh(b.list(inner)), ang), off), -ang * 0.5)
+            objs.append(o)
+        roots.append(b.finish(b.bvh(b.list(objs), 0.0, 1.0)))
+    return builders, roots
+
+
+def random_rays(rng, n):
+    rays = np.zeros(n, dtype=abi.RAY_DTYPE)
+    rays["o"] = rng.uniform(-6, 6, (n, 3))
+    d = rng.normal(size=(n, 3)) * rng.uniform(0.1, 3.0, (n, 1))
+    axis = rng.integers(0, 8, n)  # some directions with exact zeros / axis aligned
+    d[axis == 0, 0] = 0.0
+    d[axis == 1, 1] = 0.0
+    d[axis == 2, 2] = 0.0
+    d[axis == 3, :2] = 0.0
+    rays["d"] = d
+    rays["tm"] = rng.uniform(0, 1, n)
+    rays["tmin"] = np.where(rng.uniform(size=n) < 0.8, 1e-4, rng.uniform(-2, 2, n))
+    rays["tmax"] = np.where(rng.uniform(size=n) < 0.8, np.inf, rng.uniform(0, 10, n))
+    rays["pixel"] = rng.integers(0, 1 << 20, n)
+    rays["sample"] = rng.integers(0, 1 << 10, n)
+    rays["bounce"] = rng.integers(0, 50, n)
+    return rays
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_random_scenes_all_primitive_kinds(gpu, orc, case):
+    rng = np.random.default_rng(1234 + case)
+    builders, (hroot, oroot) = random_scene_pair(rng, gpu, orc, n_obj=int(rng.integers(4, 40)))
+    hs = lib.HostScene(gpu, hroot)
+    ds = lib.DeviceScene(hs)
+    rays = random_rays(rng, 20000)
+    oh, orec, _ = orc.trace(oroot, rays, seed=77, mode=oracle.AABB_TIGHT, records=True)
+    gh, _ = ds.trace(rays, seed=77)
+    compare_hits(oh, gh, "random scene %d" % case)
+    grec = ds.trace_records(rays, seed=77)
+    hit = oh["prim_id"] != abi.RT_MISS
+    assert hit.sum() > 200
+    assert np.array_equal(orec["front_face"], grec["front_face"])
+    assert np.allclose(orec["normal"][hit], grec["normal"][hit], rtol=0, atol=1e-15)
+    assert np.allclose(orec["p"][hit], grec["p"][hit], rtol=1e-13, atol=1e-11)
+    ds.close()
+    hs.close()
+    orc.api.scene_free(oroot)
+
+
+def test_edge_cases(gpu, orc):
+    b = gpu.host.builder()
+    ob = orc.api.builder()
+    roots = []
+    for bb in (b, ob):
+        m = bb.lambertian([0.5, 0.5, 0.5])
+        ground = bb.sphere([0, -1000, 0], 1000.0, m)        # the catastrophic-cancellation case of src/hittable.rs:77
+        flat = bb.triangle([1, 5, 0], [0, 6, 0], [0, 5, 0], m)  # z-flat triangle: alone in a span-1 node it is invisible
+        roots.append(bb.finish(bb.bvh(bb.list([ground, flat, bb.sphere([0, 1, 0], 1.0, m)]))))
+    hs = lib.HostScene(gpu, roots[0])
+    ds = lib.DeviceScene(hs)
+    # no rays at all
+    hits, _ = ds.trace(np.zeros(0, dtype=abi.RAY_DTYPE))
+    assert len(hits) == 0
+    rng = np.random.default_rng(5)
+    n = 4096
+    rays = np.zeros(n, dtype=abi.RAY_DTYPE)
+    rays["tmin"], rays["tmax"] = 1e-4, np.inf
+    # grazing rays over the huge ground sphere, rays from inside the unit sphere, rays at the flat triangle
+    rays["o"][: n // 2] = np.c_[rng.uniform(-50, 50, n // 2), rng.uniform(1e-6, 0.5, n // 2), rng.uniform(-50, 50, n // 2)]
+    rays["d"][: n // 2] = np.c_[rng.uniform(-1, 1, n // 2), rng.uniform(-0.2, 1e-3, n // 2), rng.uniform(-1, 1, n // 2)]
+    rays["o"][n // 2: 3 * n // 4] = [0, 1, 0]
+    rays["d"][n // 2: 3 * n // 4] = rng.normal(size=(n // 4, 3))
+    rays["o"][3 * n // 4:] = np.c_[rng.uniform(0, 1, n // 4), rng.uniform(5, 6, n // 4), np.full(n // 4, 2.0)]
+    rays["d"][3 * n // 4:] = [0, 0, -1]
+    rays[-1]["tmax"] = 0.5  # empty range
+    rays[-2]["tmin"], rays[-2]["tmax"] = 3.0, 1.0  # inverted range
+    oh, _, _ = orc.trace(roots[1], rays, mode=oracle.AABB_TIGHT)
+    gh, _ = ds.trace(rays)
+    d = compare_hits(oh, gh, "edge cases")
+    assert d.max(initial=0) == 0
+    assert (gh["prim_id"][: n // 2] != abi.RT_MISS).sum() > 500
+    assert (gh["prim_id"][n // 2: 3 * n // 4] == 2).all()  # from inside: the far root
+    ds.close()
+    hs.close()
+    orc.api.scene_free(roots[1])
+
+
+def test_device_resident_entry_point(gpu):
+    import torch
+    g = load_golden(9)
+    hs = lib.HostScene.build(9, seed=SEED, **scene_kwargs(9))
+    ds = lib.DeviceScene(hs)
+    rays = torch.from_numpy(g["rays"].view(np.uint8).copy()).cuda()
+    out = torch.zeros(len(g["rays"]) * abi.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        gpu.check(gpu.lib.rt_trace_closest_device(ds.h, rays.data_ptr(), len(g["rays"]), SEED, out.data_ptr(), stream.cuda_stream))
+    stream.synchronize()
+    dev = out.cpu().numpy().view(abi.HIT_DTYPE)
+    host, _ = ds.trace(g["rays"], seed=SEED)
+    assert np.array_equal(dev, host)
+    ds.close()
+    hs.close()

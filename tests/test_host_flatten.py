@@ -1,0 +1,202 @@
+"""Host logic: the scene-construction API, BVHNode::new and the flattener (no GPU)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import SCENE_OPTS, SEED, scene_kwargs
+from raytracer_amd import abi, lib
+from raytracer_amd.hostapi import HostApiError
+
+K = {v: k for k, v in abi.NODE_KINDS.items()}
+
+
+def walk_subtree_end(nodes, i):
+    """Index one past the subtree rooted at entry i, derived from the structure alone."""
+    kind = int(nodes["meta"][i]) & 15
+    if kind == K["inner"] or kind == K["medium"]:
+        return int(nodes["link"][i])
+    if kind == K["xf_enter"]:
+        depth = 1
+        j = i + 1
+        while depth:
+            k = int(nodes["meta"][j]) & 15
+            depth += (k == K["xf_enter"]) - (k == K["xf_exit"])
+            j += 1
+        return j
+    return i + 1
+
+
+@pytest.mark.parametrize("sid", sorted(SCENE_OPTS))
+def test_flatten_structure(rtlib, orc, sid):
+    hs = lib.HostScene.build(sid, seed=SEED, **scene_kwargs(sid))
+    nodes = hs.table("nodes")
+    n = len(nodes)
+    kinds = nodes["meta"] & 15
+    idx = nodes["meta"] >> 4
+    assert kinds[0] == K["inner"] and nodes["link"][0] == n  # the world is a BVHNode spanning the stream
+    # every inner node: 1 or 2 children exactly filling [i+1, link); its f32 box contains inner children's boxes
+    for i in np.nonzero(kinds == K["inner"])[0]:
+        end = int(nodes["link"][i])
+        assert i < end <= n
+        c1 = walk_subtree_end(nodes, i + 1)
+        assert c1 <= end
+        if c1 < end:
+            assert walk_subtree_end(nodes, c1) == end
+        for c in (i + 1, c1):
+            if c < end and kinds[c] == K["inner"] and np.isfinite(nodes["lo"][c]).all() and np.isfinite(nodes["lo"][i]).all():
+                assert (nodes["lo"][i] <= nodes["lo"][c]).all() and (nodes["hi"][i] >= nodes["hi"][c]).all()
+    # table indices in range, one table entry per distinct object, creation-order ids form a permutation
+    ids = []
+    for kind, tab in (("sphere", "spheres"), ("msphere", "msphere"), ("rect", "rects"), ("box6", "boxes"),
+                      ("triangle", "triangles"), ("medium", "media")):
+        t = hs.table(tab)
+        sel = kinds == K[kind]
+        if sel.any():
+            assert idx[sel].max() < len(t)
+            assert set(idx[sel].tolist()) == set(range(len(t)))
+            ids += t["prim_id"].tolist()
+    osc = orc.api.scene_build(sid, seed=SEED, **scene_kwargs(sid))
+    assert sorted(ids) == list(range(orc.lib.orc_scene_prim_count(osc)))
+    orc.api.scene_free(osc)
+    # wrappers: enter/exit balanced, depth and ancestors consistent
+    xf = hs.table("xforms")
+    stack = []
+    for i in range(n):
+        if kinds[i] == K["xf_enter"]:
+            x = xf[idx[i]]
+            assert x["depth"] == len(stack) + 1 and list(x["anc"][: len(stack)]) == stack and x["anc"][len(stack)] == idx[i]
+            stack.append(int(idx[i]))
+        elif kinds[i] == K["xf_exit"]:
+            assert stack.pop() == idx[i]
+    assert not stack
+    hs.close()
+
+
+def test_cornell_box_layout(rtlib):
+    # src/main.rs:459-517: 6 rects, two Translate(RotateY(Box6)), one world BVH
+    hs = lib.HostScene.build(7)
+    d = hs.desc
+    assert (d.n_rects, d.n_boxes, d.n_xforms, d.n_media, d.n_spheres) == (6, 2, 4, 0, 0)
+    rects = hs.table("rects")
+    light = rects[rects["prim_id"] == 2][0]
+    assert (light["a0"], light["a1"], light["b0"], light["b1"], light["k"], light["axis"]) == (213.0, 343.0, 227.0, 332.0, 554.0, 1)
+    mats = hs.table("materials")
+    tex = hs.table("textures")
+    lm = mats[light["mat"]]
+    assert lm["kind"] == 3 and tex[lm["tex"]]["a"].tolist() == [15.0, 15.0, 15.0]
+    xf = hs.table("xforms")
+    rot = xf[xf["kind"] == 1]
+    assert np.allclose(np.sort(rot["sin_theta"]), np.sort(np.sin(np.radians([15.0, -18.0]))), rtol=0, atol=1e-15)
+    hs.close()
+
+
+def test_final_scene_layout(rtlib):
+    # src/main.rs:587-699: 400 boxes, 1 light rect, 1 moving sphere, 105 spheres (the r=70 boundary appears twice in the
+    # stream but once in the table), 2 media, 1 noise texture, 1 image texture
+    hs = lib.HostScene.build(9, **scene_kwargs(9))
+    d = hs.desc
+    assert (d.n_boxes, d.n_rects, d.n_msphere, d.n_spheres, d.n_media, d.n_perlins, d.n_images) == (400, 1, 1, 106, 2, 1, 1)
+    nodes = hs.table("nodes")
+    assert int(((nodes["meta"] & 15) == K["sphere"]).sum()) == 107
+    mats = hs.table("materials")
+    metal = mats[mats["kind"] == 1][0]
+    assert metal["param"] == 1.0  # fuzz 10.0 clamped (src/material.rs:62)
+    med = hs.table("media")
+    assert sorted(med["neg_inv_density"].tolist()) == [-1.0 / 0.0001, -1.0 / 0.02]
+    assert d.n_texel_bytes == 1024 * 512 * 3
+    hs.close()
+
+
+def test_scene_and_camera_constants_match_oracle(rtlib, orc):
+    for sid in sorted(SCENE_OPTS):
+        a = rtlib.host.scene_setup(sid)
+        b = orc.api.scene_setup(sid)
+        assert bytes(a) == bytes(b)
+        assert bytes(rtlib.host.camera(a)) == bytes(orc.api.camera(b))
+    with pytest.raises(HostApiError):
+        rtlib.host.scene_setup(99)
+    with pytest.raises(HostApiError):
+        rtlib.host.scene_build(99)
+
+
+def test_camera_known_values(rtlib):
+    # Camera::new (src/camera.rs:27-59) for the Cornell view: w = -z, u = -x... with vfov 40, aspect 1
+    cam = rtlib.host.camera_new([278, 278, -800], [278, 278, 0], [0, 1, 0], 40.0, 1.0, 0.0, 10.0)
+    h = np.tan(np.radians(40.0) / 2)
+    assert list(cam.u) == [-1.0, 0.0, 0.0] and list(cam.v) == [0.0, 1.0, 0.0]
+    assert np.allclose(list(cam.horizontal), [-20 * h, 0, 0]) and np.allclose(list(cam.vertical), [0, 20 * h, 0])
+    assert cam.lens_radius == 0.0
+    with pytest.raises(HostApiError):  # lookfrom == lookat: unit() of zero (src/vec3.rs:285-286 panics)
+        rtlib.host.camera_new([1, 1, 1], [1, 1, 1], [0, 1, 0], 40.0, 1.0, 0.0, 10.0)
+
+
+def test_same_seed_same_scene_other_seed_other_scene(rtlib):
+    a = lib.HostScene.build(1, seed=1)
+    b = lib.HostScene.build(1, seed=1)
+    c = lib.HostScene.build(1, seed=2)
+    assert a.table("nodes").tobytes() == b.table("nodes").tobytes()
+    assert a.table("msphere").tobytes() == b.table("msphere").tobytes()
+    assert a.table("msphere").tobytes() != c.table("msphere").tobytes()
+    for s in (a, b, c):
+        s.close()
+
+
+def test_builder_span_one_and_shared_objects(rtlib):
+    b = rtlib.host.builder()
+    m = b.metal([0.8, 0.8, 0.8], 0.01)
+    box = b.box6([0, 0, 0], [3, 20, 0.1], m)
+    tri = b.triangle([2.5, 22, -0.1], [1.5, 20, -0.86], [1.9, 20, -1.5], b.lambertian([1, 0.45, 0.45]))
+    objs = [box, b.translate(b.rotate_y(box, 60.0), [0, 0, 0]), tri]
+    hs = lib.HostScene(rtlib, b.finish(b.bvh(b.list(objs))))
+    nodes = hs.table("nodes")
+    kinds = (nodes["meta"] & 15).tolist()
+    # 3 objects: the BVH has a span-1 node (left == right, emitted once) and a span-2 node
+    assert kinds.count(K["inner"]) == 3 and kinds.count(K["box6"]) == 2 and hs.desc.n_boxes == 1
+    assert hs.desc.n_xforms == 2
+    xf = hs.table("xforms")
+    assert xf["kind"].tolist() == [0, 1] and xf["depth"].tolist() == [1, 2] and xf["inst_id"].tolist() == [1, 0]
+    hs.close()
+
+
+def test_builder_errors(rtlib):
+    b = rtlib.host.builder()
+    with pytest.raises(HostApiError):
+        b.sphere([0, 0, 0], 1.0, 5)  # bad material handle
+    with pytest.raises(HostApiError):
+        b.bvh(b.list())  # BVHNode::new on an empty list (the reference would recurse forever / index out of bounds)
+    m = b.lambertian([0.5, 0.5, 0.5])
+    s = b.sphere([0, 0, 0], 1.0, m)
+    inner = b.constant_medium(s, 0.1, [1, 1, 1])
+    outer = b.constant_medium(inner, 0.1, [1, 1, 1])
+    with pytest.raises(HostApiError):
+        b.finish(b.bvh(b.list([outer])))  # medium inside a medium boundary is rejected
+    o = s
+    for _ in range(5):
+        o = b.translate(o, [1, 0, 0])
+    with pytest.raises(HostApiError):
+        b.finish(b.bvh(b.list([o])))  # more than 4 nested wrappers
+    with pytest.raises(HostApiError):
+        b.finish(999)
+
+
+def test_flat_box_is_stored_inverted(rtlib):
+    # An axis-aligned triangle alone in a span-1 node has a flat box, which the reference's test never passes
+    # (src/aabb.rs:25); it is stored as an inverted box so that the f32 rounding cannot give it thickness.
+    b = rtlib.host.builder()
+    m = b.lambertian([0.5, 0.5, 0.5])
+    tri = b.triangle([1, 0, 0.1], [0, 1, 0.1], [0, 0, 0.1], m)
+    hs = lib.HostScene(rtlib, b.finish(b.bvh(b.list([tri]))))
+    n0 = hs.table("nodes")[0]
+    assert np.isposinf(n0["lo"]).all() and np.isneginf(n0["hi"]).all()
+    hs.close()
+
+
+def test_mesh_scene_counts(rtlib):
+    hs = lib.HostScene.build(12, n_triangles=5000)
+    G = int(np.ceil(np.sqrt(5000 / 8.0)))
+    assert hs.desc.n_triangles == 1 + 8 * G * G
+    assert hs.desc.n_materials == 2 + 64
+    tri = hs.table("triangles")
+    assert np.isfinite(tri["e1"]).all() and (np.abs(np.cross(tri["e1"], tri["e2"])).sum(1) > 0).all()
+    hs.close()

@@ -1,0 +1,71 @@
+"""The oracle against the committed golden vectors (tests/golden, made by tools/make_golden.py):
+closest-hit ids, raw bits of t and full hit records on ~4096 harvested rays per scene. Pins the
+oracle (and the libm it links) against regressions; these are not outputs of the Rust reference,
+which holds no vectors for this path."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, SCENE_OPTS, SEED, load_golden, scene_kwargs
+
+
+@pytest.mark.parametrize("sid", sorted(SCENE_OPTS))
+def test_oracle_reproduces_golden(orc, sid):
+    g = load_golden(sid)
+    sc = orc.api.scene_build(sid, seed=SEED, **scene_kwargs(sid))
+    hits, recs, stats = orc.trace(sc, g["rays"], seed=SEED, mode=oracle.AABB_TIGHT, records=True)
+    assert np.array_equal(hits["prim_id"], g["hits"]["prim_id"])
+    assert np.array_equal(hits["sub"], g["hits"]["sub"])
+    assert np.array_equal(hits["t"].view(np.uint64), g["hits"]["t"].view(np.uint64))
+    for f in ("p", "normal", "u", "v"):
+        assert np.array_equal(recs[f], g["records"][f]), f
+    assert np.array_equal(recs["front_face"], g["records"]["front_face"])
+    with open(os.path.join(GOLDEN, "meta.json")) as f:
+        meta = json.load(f)["scenes"][str(sid)]
+    assert stats["box_tests"] == meta["box_tests_tight"]
+    # the reference's own (looser) box test must agree on every scene whose boxes bound their contents
+    hits_ref, _, _ = orc.trace(sc, g["rays"], seed=SEED, mode=oracle.AABB_REFERENCE)
+    assert np.array_equal(hits_ref["prim_id"], g["hits_reference_aabb"]["prim_id"])
+    if sid != 1:  # random_scene builds its BVH over t in (0, 0.1) while the shutter is (0, 1): src/main.rs:315 vs :177-178
+        assert np.array_equal(hits_ref["prim_id"], hits["prim_id"])
+        assert np.array_equal(hits_ref["t"].view(np.uint64), hits["t"].view(np.uint64))
+    orc.api.scene_free(sc)
+
+
+def test_weekend_shutter_times_make_box_tests_agree(orc):
+    # With the BVH built over the shutter interval the moving-sphere boxes bound the spheres, and then the
+    # reference's loose test and the carried slab test must give the same closest hits.
+    from raytracer_amd import abi
+    g = load_golden(1)
+    sc = orc.api.scene_build(1, seed=SEED, flags=abi.RT_SCENE_BVH_SHUTTER_TIMES)
+    a, _, sa = orc.trace(sc, g["rays"], seed=SEED, mode=oracle.AABB_TIGHT)
+    b, _, sb = orc.trace(sc, g["rays"], seed=SEED, mode=oracle.AABB_REFERENCE)
+    assert np.array_equal(a, b)
+    assert sa["box_tests"] < sb["box_tests"]
+    orc.api.scene_free(sc)
+
+
+def test_analytic_sphere_rect_triangle(orc):
+    # hand-computed cases following src/hittable.rs:72-113, src/aarect.rs:30-48, src/triangle.rs:26-69
+    from raytracer_amd import abi
+    b = orc.api.builder()
+    m = b.lambertian([0.5, 0.5, 0.5])
+    objs = [b.sphere([0, 0, -5], 1.0, m), b.xy_rect(-1, 1, -1, 1, -10.0, m),
+            b.triangle([11, 0, -3], [10, 1, -3], [10, 0, -3], m), b.sphere([100, 100, 100], 1.0, m)]
+    root = b.bvh(b.list(objs))
+    sc = b.finish(root)
+    rays = np.zeros(4, dtype=abi.RAY_DTYPE)
+    rays["tmin"] = 1e-4
+    rays["tmax"] = np.inf
+    rays["d"] = [[0, 0, -1], [0, 0, -2], [0, 0, -1], [0, 0, 1]]
+    rays["o"] = [[0, 0, 0], [0.5, 0.875, 0], [10.25, 0.25, 0], [0, 0, 0]]
+    hits, recs, _ = orc.trace(sc, rays, records=True)
+    assert hits["prim_id"].tolist() == [0, 1, 2, abi.RT_MISS]
+    assert hits["t"][0] == 4.0 and hits["t"][1] == 5.0 and hits["t"][2] == 3.0
+    assert recs["normal"][0].tolist() == [0, 0, 1] and recs["front_face"][0] == 1
+    assert (hits["u"][1], hits["v"][1]) == (0.75, 0.9375)  # (x - x0)/(x1 - x0), (y - y0)/(y1 - y0)
+    assert (hits["u"][2], hits["v"][2]) == (0.25, 0.25)  # barycentrics
+    orc.api.scene_free(sc)
