@@ -216,6 +216,11 @@ int rt_render(RtScene* scene, const RtCamera* cam, const RtRenderParams* params,
 int rt_render_device(RtScene* scene, const RtCamera* cam, const RtRenderParams* params, float* accum_rgb_dev, void* stream,
                      RtRenderStats* stats);
 
+/* Instrumented rt_render_device: same image, and the traversal work of all extend launches of the call summed
+ * into work[10] (layout as in rt_trace_work). Waits for completion. Used to derive algorithmic bytes per ray. */
+int rt_render_work(RtScene* scene, const RtCamera* cam, const RtRenderParams* params, float* accum_rgb_dev, void* stream,
+                   RtRenderStats* stats, uint64_t* work);
+
 /* Replaces the gamma / clamp / u8 conversion (src/main.rs:212-225): out =
  * clamp(sqrt(accum / spp), 0, 0.999) * 255 as u8. Host buffers / device buffers. */
 int rt_resolve_u8(const float* accum_rgb, uint32_t width, uint32_t height, uint64_t spp, uint8_t* rgb_out);

@@ -195,7 +195,7 @@ int check_render_args(const RtScene* s, const RtCamera* cam, const RtRenderParam
 }
 
 int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* accum_dev, hipStream_t stream,
-                     RtRenderStats* stats) {
+                     RtRenderStats* stats, uint64_t* work = nullptr) {
     if (int rc = bind_device(s)) return rc;
     const uint64_t npix = (uint64_t)p->width * p->height;
     const uint32_t total = p->sample_end - p->sample_begin;
@@ -223,7 +223,7 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         w.events.push_back(e);
     }
     size_t ev = 0;
-    HIP_TRY(hipMemsetAsync(w.ray_total, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(w.ray_total, 0, (1 + kWorkWords) * sizeof(unsigned long long), stream));
     if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
     for (uint32_t b = 0; b < n_batches; ++b) {
         const uint32_t s0 = p->sample_begin + b * spb;
@@ -237,8 +237,12 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
             const uint32_t* q = bounce == 0 ? nullptr : w.queue[cur];
             HIP_TRY(hipMemsetAsync(w.counts + nxt, 0, sizeof(uint32_t), stream));
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
-            hipLaunchKernelGGL(rtd::k_extend<false>, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts + cur, bounce,
-                               (unsigned long long*)nullptr);
+            if (work)
+                hipLaunchKernelGGL(rtd::k_extend<true>, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts + cur, bounce,
+                                   w.ray_total + 1);
+            else
+                hipLaunchKernelGGL(rtd::k_extend<false>, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts + cur, bounce,
+                                   (unsigned long long*)nullptr);
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
             hipLaunchKernelGGL(rtd::k_shade, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts + cur, w.queue[nxt],
                                w.counts + nxt, bounce, w.ray_total);
@@ -265,6 +269,12 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         stats->rays = rays;
         stats->paths = npix * total;
         stats->batches = n_batches;
+    }
+    if (work) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        unsigned long long tmp[kWorkWords];
+        HIP_TRY(hipMemcpy(tmp, w.ray_total + 1, sizeof tmp, hipMemcpyDeviceToHost));
+        for (int k = 0; k < kWorkWords; ++k) work[k] = tmp[k];
     }
     return RT_OK;
 }
@@ -412,6 +422,13 @@ int rt_trace_work(RtScene* s, const RtRay* rays, uint64_t n, uint64_t seed, RtHi
 int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* accum_dev, void* stream, RtRenderStats* stats) {
     if (int rc = check_render_args(s, cam, p, accum_dev)) return rc;
     return render_on_stream(s, cam, p, accum_dev, (hipStream_t)stream, stats);
+}
+
+int rt_render_work(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* accum_dev, void* stream, RtRenderStats* stats,
+                   uint64_t* work) {
+    if (!work) return rt::set_error(RT_E_INVALID, "null argument");
+    if (int rc = check_render_args(s, cam, p, accum_dev)) return rc;
+    return render_on_stream(s, cam, p, accum_dev, (hipStream_t)stream, stats, work);
 }
 
 int rt_render(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* accum_rgb, RtRenderStats* stats) {

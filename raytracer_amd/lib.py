@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "librt_hip.so")
 
 ABI_SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_trace_closest",
-    "rt_trace_records", "rt_trace_closest_device", "rt_trace_work", "rt_render", "rt_render_device", "rt_resolve_u8",
+    "rt_trace_records", "rt_trace_closest_device", "rt_trace_work", "rt_render", "rt_render_device", "rt_render_work",
+    "rt_resolve_u8",
     "rt_resolve_u8_device",
 )
 HOST_SYMBOLS = (
@@ -55,6 +56,7 @@ class Library:
         L.rt_trace_work.argtypes = [vp, vp, u64, u64, vp, P(u64)]
         L.rt_render.argtypes = [vp, P(abi.RtCamera), P(abi.RtRenderParams), vp, P(abi.RtRenderStats)]
         L.rt_render_device.argtypes = [vp, P(abi.RtCamera), P(abi.RtRenderParams), vp, vp, P(abi.RtRenderStats)]
+        L.rt_render_work.argtypes = [vp, P(abi.RtCamera), P(abi.RtRenderParams), vp, vp, P(abi.RtRenderStats), P(u64)]
         L.rt_resolve_u8.argtypes = [vp, u32, u32, u64, vp]
         L.rt_resolve_u8_device.argtypes = [vp, u32, u32, u64, vp, vp]
         for name in ABI_SYMBOLS:
@@ -175,6 +177,16 @@ class DeviceScene:
         """rt_render_device: accum_ptr is a device address (int), stream a hipStream_t handle (int) or None."""
         self.lib.check(self.lib.lib.rt_render_device(self.h, C.byref(cam), C.byref(params), C.c_void_p(accum_ptr),
                                                     C.c_void_p(stream or 0), C.byref(stats) if stats is not None else None))
+
+
+    def render_work(self, cam, params, accum_ptr, stream=None):
+        """rt_render_work: returns (stats, work dict) for an instrumented render into a device buffer."""
+        st = abi.RtRenderStats()
+        work = (C.c_uint64 * 10)()
+        self.lib.check(self.lib.lib.rt_render_work(self.h, C.byref(cam), C.byref(params), C.c_void_p(accum_ptr),
+                                                  C.c_void_p(stream or 0), C.byref(st), work))
+        w = list(work)
+        return st, {"entries": w[0], **{abi.NODE_KINDS[k]: w[1 + k] for k in range(9)}}
 
 
 def make_params(width, height, s0, s1, background, seed=0x5EED, max_depth=50, samples_per_batch=0):
