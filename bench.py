@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="final", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the CPU baseline run (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=8, help="the reference's own thread count (src/main.rs:189)")
     args = ap.parse_args()

@@ -54,7 +54,8 @@ RT_D void fill_rect_record(HitRec& rec, V3 o, V3 d, double t, uint32_t axis, dou
 }
 
 // ow, dw, tm: the ray handed to world.hit. `best` must be a hit.
-RT_D void build_hit_record(const DevScene& S, V3 ow, V3 dw, double tm, const Cand& best, HitRec& rec) {
+// want_uv = false skips the spherical u, v (atan2, asin), which only an image texture reads (src/texture.rs:93-98).
+RT_D void build_hit_record(const DevScene& S, V3 ow, V3 dw, double tm, const Cand& best, HitRec& rec, bool want_uv = true) {
     const uint32_t kind = best.ref & 15u;
     const uint32_t idx = best.ref >> 4;
     const uint32_t xf1 = best.aux >> 8;
@@ -73,7 +74,7 @@ RT_D void build_hit_record(const DevScene& S, V3 ow, V3 dw, double tm, const Can
             rec.p = at(o, d, t);
             const V3 outward_normal = (rec.p - c) / s->r;
             set_face_normal(rec, d, outward_normal);
-            get_sphere_uv(outward_normal, rec.u, rec.v);
+            if (want_uv) get_sphere_uv(outward_normal, rec.u, rec.v);
             rec.mat = s->mat;
             break;
         }
@@ -147,6 +148,19 @@ RT_D void build_hit_record(const DevScene& S, V3 ow, V3 dw, double tm, const Can
             rec.p = p;
             set_face_normal(rec, dl, normal);
         }
+    }
+}
+
+// Material of the winning candidate without building the record.
+RT_D uint32_t hit_material(const DevScene& S, const Cand& best) {
+    const uint32_t idx = best.ref >> 4;
+    switch (best.ref & 15u) {
+        case RT_N_SPHERE: return S.spheres[idx].mat;
+        case RT_N_MSPHERE: return S.msphere[idx].mat;
+        case RT_N_RECT: return S.rects[idx].mat;
+        case RT_N_BOX6: return S.boxes[idx].mat;
+        case RT_N_TRIANGLE: return S.triangles[idx].mat;
+        default: return S.media[idx].mat;
     }
 }
 

@@ -36,52 +36,139 @@ struct RenderConst {
 
 constexpr int BLOCK = 256;
 
-// ---- stand-alone closest hit (rt_trace_closest / rt_trace_records) ---------------------
-template <bool RECORDS, bool COUNT>
-__global__ void __launch_bounds__(BLOCK) k_trace(DevScene S, const RtRay* __restrict__ rays, uint64_t n, uint64_t seed,
-                                                 RtHit* __restrict__ hits, RtHitRecord* __restrict__ recs,
-                                                 unsigned long long* __restrict__ work_out) {
+// minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument)
+#ifndef RT_EXTEND_WAVES
+#define RT_EXTEND_WAVES 3
+#endif
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 2
+#endif
+
+// ---- persistent closest-hit loop ----------------------------------------------------------
+// Rays of one launch form a pool; every wave pulls rays from it through one shared cursor and keeps its
+// lanes busy: a lane whose query has finished stores its result and, as soon as enough lanes of the wave are
+// idle, the idle lanes pull new rays together (one atomic per refill) while the other lanes keep their
+// half-finished queries. Per step the wave runs box tests until every busy lane stands on a primitive /
+// wrapper / medium entry, then handles those entries. This removes the two big sources of idle lanes of a
+// one-ray-per-thread loop: waiting for the longest query of the wave, and box tests interleaved with
+// primitive tests.
+//
+// IO supplies the pool: n(), fetch(index, ...) and store(index, ...).
+constexpr uint32_t REFILL_LANES = 16;  // refill when at least this many lanes are idle
+
+template <bool COUNT, class IO>
+RT_D void extend_pool(const DevScene& S, IO& io, uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
     Work work;
     if (COUNT) { work.entries = 0; for (int k = 0; k < 9; ++k) work.prim[k] = 0; }
-    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-        const RtRay* q = rays + i;
-        const V3 o = v3p(q->o), d = v3p(q->d);
-        const double tm = q->tm;
-        RayKey key;
-        key.seed = seed; key.pixel = q->pixel; key.sample = q->sample; key.bounce = q->bounce;
-        Cand best;
-        closest_hit<true, COUNT>(S, o, d, tm, q->tmin, q->tmax, 0u, S.n_nodes, 0u, 0u, key, best, &work);
-        if (RECORDS) {
-            RtHitRecord r;
-            r.prim_id = RT_MISS; r.sub = 0u; r.mat = RT_NONE; r.front_face = 0u;
-            r.t = 0.0; r.u = 0.0; r.v = 0.0;
-            for (int k = 0; k < 3; ++k) { r.p[k] = 0.0; r.normal[k] = 0.0; }
-            if (best.ref != RT_MISS) {
-                HitRec rec;
-                build_hit_record(S, o, d, tm, best, rec);
-                hit_ids(S, best, r.prim_id, r.sub);
-                r.p[0] = rec.p.x; r.p[1] = rec.p.y; r.p[2] = rec.p.z;
-                r.normal[0] = rec.normal.x; r.normal[1] = rec.normal.y; r.normal[2] = rec.normal.z;
-                r.t = rec.t; r.u = rec.u; r.v = rec.v; r.mat = rec.mat; r.front_face = rec.front_face ? 1u : 0u;
+    const uint32_t n = io.n();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total_waves = gridDim.x * (BLOCK / 64);
+    // with few rays, spread them over the waves of the grid instead of filling a few waves completely
+    uint32_t max_active = (n + total_waves - 1u) / total_waves;
+    max_active = max_active < 8u ? 8u : (max_active > 64u ? 64u : max_active);
+    const uint32_t refill_at = REFILL_LANES < max_active ? REFILL_LANES : max_active;
+    Walker<COUNT> w;
+    w.done = true;
+    typename IO::Ray ray;
+    uint32_t index = 0u;
+    bool busy = false;
+    bool exhausted = false;  // wave-uniform
+    for (;;) {
+        const unsigned long long act = __ballot(busy);
+        const uint32_t n_act = (uint32_t)__popcll(act);
+        if (!exhausted) {
+            const uint32_t room = max_active > n_act ? max_active - n_act : 0u;
+            if (room >= refill_at || (n_act == 0u && room > 0u)) {
+                const uint32_t my_rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
+                uint32_t base = 0u;
+                if (lane == 0u) base = atomicAdd(cursor, room);
+                base = __shfl(base, 0, 64);
+                if (!busy && my_rank < room && base + my_rank < n) {
+                    index = base + my_rank;
+                    io.fetch(index, ray);
+                    w.init(S, ray.o, ray.d, ray.tm, ray.tmin, ray.tmax);
+                    busy = true;
+                }
+                exhausted = base + room >= n;
             }
-            recs[i] = r;
-        } else {
-            RtHit h;
-            h.prim_id = RT_MISS; h.sub = 0u; h.t = 0.0; h.u = 0.0; h.v = 0.0;
-            if (best.ref != RT_MISS) {
-                HitRec rec;
-                build_hit_record(S, o, d, tm, best, rec);
-                hit_ids(S, best, h.prim_id, h.sub);
-                h.t = rec.t; h.u = rec.u; h.v = rec.v;
+        }
+        if (__ballot(busy) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (busy) {
+            w.box_run(S, ray.key, &work);
+            if (!w.done) w.leaf(S, ray.rs, ray.key, &work);
+            if (w.done) {
+                io.store(S, index, ray, w.best);
+                busy = false;
             }
-            hits[i] = h;
         }
     }
     if (COUNT) {
         atomicAdd(work_out + 0, (unsigned long long)work.entries);
         for (int k = 0; k < 9; ++k) atomicAdd(work_out + 1 + k, (unsigned long long)work.prim[k]);
     }
+}
+
+// ---- stand-alone closest hit (rt_trace_closest / rt_trace_records) ---------------------
+template <bool RECORDS>
+struct TraceIO {
+    const RtRay* rays;
+    uint64_t n_rays, seed;
+    RtHit* hits;
+    RtHitRecord* recs;
+    struct Ray {
+        V3 o, d;
+        double tm, tmin, tmax;
+        RayKey key;
+        RayAoS rs;
+    };
+    RT_D uint32_t n() const { return (uint32_t)n_rays; }
+    RT_D void fetch(uint32_t i, Ray& r) const {
+        const RtRay* q = rays + i;
+        r.o = v3p(q->o); r.d = v3p(q->d); r.tm = q->tm; r.tmin = q->tmin; r.tmax = q->tmax;
+        r.key.seed = seed; r.key.pixel = q->pixel; r.key.sample = q->sample; r.key.bounce = q->bounce;
+        r.rs.r = q;
+    }
+    RT_D void store(const DevScene& S, uint32_t i, const Ray& r, const Cand& best) const {
+        V3 o, d;
+        r.rs.load(o, d);
+        if (RECORDS) {
+            RtHitRecord out;
+            out.prim_id = RT_MISS; out.sub = 0u; out.mat = RT_NONE; out.front_face = 0u;
+            out.t = 0.0; out.u = 0.0; out.v = 0.0;
+            for (int k = 0; k < 3; ++k) { out.p[k] = 0.0; out.normal[k] = 0.0; }
+            if (best.ref != RT_MISS) {
+                HitRec rec;
+                build_hit_record(S, o, d, r.tm, best, rec);
+                hit_ids(S, best, out.prim_id, out.sub);
+                out.p[0] = rec.p.x; out.p[1] = rec.p.y; out.p[2] = rec.p.z;
+                out.normal[0] = rec.normal.x; out.normal[1] = rec.normal.y; out.normal[2] = rec.normal.z;
+                out.t = rec.t; out.u = rec.u; out.v = rec.v; out.mat = rec.mat; out.front_face = rec.front_face ? 1u : 0u;
+            }
+            recs[i] = out;
+        } else {
+            RtHit h;
+            h.prim_id = RT_MISS; h.sub = 0u; h.t = 0.0; h.u = 0.0; h.v = 0.0;
+            if (best.ref != RT_MISS) {
+                HitRec rec;
+                build_hit_record(S, o, d, r.tm, best, rec);
+                hit_ids(S, best, h.prim_id, h.sub);
+                h.t = rec.t; h.u = rec.u; h.v = rec.v;
+            }
+            hits[i] = h;
+        }
+    }
+};
+
+template <bool RECORDS, bool COUNT>
+__global__ void __launch_bounds__(BLOCK) k_trace(DevScene S, const RtRay* __restrict__ rays, uint64_t n, uint64_t seed,
+                                                 RtHit* __restrict__ hits, RtHitRecord* __restrict__ recs,
+                                                 uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
+    TraceIO<RECORDS> io;
+    io.rays = rays; io.n_rays = n; io.seed = seed; io.hits = hits; io.recs = recs;
+    extend_pool<COUNT>(S, io, cursor, work_out);
 }
 
 // ---- generate: camera rays of one batch (src/main.rs:206-209, src/camera.rs:61-71) ---------
@@ -104,42 +191,60 @@ __global__ void __launch_bounds__(BLOCK) k_generate(RenderConst C, PathState P) 
 
 // ---- extend ------------------------------------------------------------------------------
 // queue == nullptr: the identity queue of bounce 0 (every slot of the batch is live).
-template <bool COUNT>
-__global__ void __launch_bounds__(BLOCK) k_extend(DevScene S, RenderConst C, PathState P, const uint32_t* __restrict__ queue,
-                                                  const uint32_t* __restrict__ count, uint32_t bounce,
-                                                  unsigned long long* __restrict__ work_out) {
-    Work work;
-    if (COUNT) { work.entries = 0; for (int k = 0; k < 9; ++k) work.prim[k] = 0; }
-    const uint32_t n = queue ? *count : C.n_slots;
-    const uint32_t stride = gridDim.x * BLOCK;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-        const uint32_t slot = queue ? queue[i] : i;
-        const V3 o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
-        const V3 d = v3(P.dx[slot], P.dy[slot], P.dz[slot]);
-        const double tm = P.tm[slot];
+struct ExtendIO {
+    RenderConst C;
+    PathState P;
+    const uint32_t* queue;
+    uint32_t count, bounce;
+    struct Ray {
+        V3 o, d;
+        double tm;
+        static constexpr double tmin = 0.0001;  // src/color.rs:41
+        static constexpr double tmax = D_INF;
         RayKey key;
-        key.seed = C.seed; key.pixel = slot % C.npix; key.sample = C.sample0 + slot / C.npix; key.bounce = bounce;
-        Cand best;
-        closest_hit<true, COUNT>(S, o, d, tm, 0.0001, D_INF, 0u, S.n_nodes, 0u, 0u, key, best, &work);  // src/color.rs:41
+        RaySoA rs;
+    };
+    RT_D uint32_t n() const { return count; }
+    RT_D void fetch(uint32_t i, Ray& r) const {
+        const uint32_t slot = queue ? queue[i] : i;
+        r.rs.ox = P.ox; r.rs.oy = P.oy; r.rs.oz = P.oz; r.rs.dx = P.dx; r.rs.dy = P.dy; r.rs.dz = P.dz; r.rs.slot = slot;
+        r.rs.load(r.o, r.d);
+        r.tm = P.tm[slot];
+        r.key.seed = C.seed; r.key.pixel = slot % C.npix; r.key.sample = C.sample0 + slot / C.npix; r.key.bounce = bounce;
+    }
+    RT_D void store(const DevScene&, uint32_t, const Ray& r, const Cand& best) const {
+        const uint32_t slot = r.rs.slot;
         P.hit_t[slot] = best.t;
         P.hit_ref[slot] = best.ref;
         P.hit_aux[slot] = best.aux;
     }
-    if (COUNT) {
-        atomicAdd(work_out + 0, (unsigned long long)work.entries);
-        for (int k = 0; k < 9; ++k) atomicAdd(work_out + 1 + k, (unsigned long long)work.prim[k]);
-    }
+};
+
+// counts[0], counts[1]: lengths of the two queues; counts[2]: the ray cursor of this launch (zero on entry,
+// reset by the shade launch that follows).
+template <bool COUNT>
+__global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DevScene S, RenderConst C, PathState P, const uint32_t* __restrict__ queue,
+                                                  uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
+                                                  unsigned long long* __restrict__ work_out) {
+    ExtendIO io;
+    io.C = C; io.P = P; io.queue = queue; io.bounce = bounce;
+    io.count = queue ? counts[cur] : C.n_slots;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[cur ^ 1u] = 0u;  // the queue the following shade launch appends to
+    extend_pool<COUNT>(S, io, counts + 2, work_out);
 }
 
 // ---- shade ---------------------------------------------------------------------------------
 // The body of ray_color after world.hit (src/color.rs:42-62), unrolled from recursion into
 // L += T * emitted; T *= attenuation. Survivors go to next_queue.
-__global__ void __launch_bounds__(BLOCK) k_shade(DevScene S, RenderConst C, PathState P, const uint32_t* __restrict__ queue,
-                                                 const uint32_t* __restrict__ count, uint32_t* __restrict__ next_queue,
-                                                 uint32_t* __restrict__ next_count, uint32_t bounce,
-                                                 unsigned long long* __restrict__ ray_total) {
-    const uint32_t n = queue ? *count : C.n_slots;
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_total, (unsigned long long)n);
+__global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DevScene S, RenderConst C, PathState P, const uint32_t* __restrict__ queue,
+                                                 uint32_t* __restrict__ counts, uint32_t cur, uint32_t* __restrict__ next_queue,
+                                                 uint32_t bounce, unsigned long long* __restrict__ ray_total) {
+    const uint32_t n = queue ? counts[cur] : C.n_slots;
+    uint32_t* next_count = counts + (cur ^ 1u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(ray_total, (unsigned long long)n);
+        counts[2] = 0u;  // ray cursor of the next extend launch
+    }
     const uint32_t stride = gridDim.x * BLOCK;
     // every lane of a wave runs the same number of iterations so that the ballot below sees whole waves
     const uint32_t n_round = (n + 63u) & ~63u;
@@ -159,15 +264,19 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene S, RenderConst C, Path
                 const V3 o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
                 const V3 d = v3(P.dx[slot], P.dy[slot], P.dz[slot]);
                 const double tm = P.tm[slot];
+                const RtMaterial* M = S.materials + hit_material(S, best);
+                const uint32_t mkind = M->kind;
+                const bool textured = material_has_texture(mkind);
+                const bool want_uv = textured && S.textures[M->tex].kind == RT_T_IMAGE;
                 HitRec rec;
-                build_hit_record(S, o, d, tm, best, rec);
-                const RtMaterial* M = S.materials + rec.mat;
-                const V3 emitted = material_emitted(S, M, rec);  // :50
-                L = L + elemul(T, emitted);
+                build_hit_record(S, o, d, tm, best, rec, want_uv);
+                V3 texv = v3(0.0, 0.0, 0.0);
+                if (textured) texv = texture_value(S, M->tex, rec.u, rec.v, rec.p);
+                if (mkind == RT_M_DIFFUSE_LIGHT) L = L + elemul(T, texv);  // emitted, :50 (zero for every other material)
                 rt::Rng rng;
                 rng.set_path(C.seed, slot % C.npix, C.sample0 + slot / C.npix, bounce, rt::RNG_SCATTER);
                 V3 attenuation = v3(0.0, 0.0, 0.0), dout = v3(1.0, 1.0, 1.0);
-                if (material_scatter(S, M, d, rec, rng, attenuation, dout)) {  // :52-57
+                if (material_scatter(M, d, rec, texv, rng, attenuation, dout)) {  // :52-57
                     T = elemul(T, attenuation);
                     alive = bounce + 1u < C.max_depth;  // ray_color(depth - 1) returns black at depth 0 (:37-39)
                     if (alive) {

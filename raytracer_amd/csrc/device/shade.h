@@ -21,7 +21,9 @@ RT_D V3 random_unit_vector(rt::Rng& rng) {  // :50-55
     const double a = rng.uniform(0.0, 2.0 * D_PI);
     const double z = rng.uniform(-1.0, 1.0);
     const double r = sqrt(1.0 - z * z);
-    return v3(r * cos(a), r * sin(a), z);
+    double sa, ca;
+    sincos(a, &sa, &ca);
+    return v3(r * ca, r * sa, z);
 }
 RT_D V3 random_in_unit_disk(rt::Rng& rng) {  // :67-75
     for (;;) {
@@ -71,6 +73,7 @@ RT_D double perlin_turb(const RtPerlin* P, V3 p, int depth) {  // :91-103
     double accum = 0.0;
     V3 temp_p = p;
     double weight = 1.0;
+#pragma unroll 1
     for (int i = 0; i < depth; ++i) {
         accum += weight * perlin_noise(P, temp_p);
         weight *= 0.5;
@@ -124,21 +127,18 @@ RT_D double schlick(double cosine, double ref_idx) {  // src/material.rs:144-148
     return r0 + (1.0 - r0) * (x * (x2 * x2));
 }
 
-// emitted (src/material.rs:17-19, 176-178)
-RT_D V3 material_emitted(const DevScene& S, const RtMaterial* M, const HitRec& rec) {
-    if (M->kind == RT_M_DIFFUSE_LIGHT) return texture_value(S, M->tex, rec.u, rec.v, rec.p);
-    return v3(0.0, 0.0, 0.0);
-}
+// Texture::value of the material's texture, evaluated once per hit: Lambertian and Isotropic use it as the
+// attenuation (src/material.rs:48, 208), DiffuseLight as the emitted radiance (:176-178).
+RT_D bool material_has_texture(uint32_t kind) { return kind == RT_M_LAMBERTIAN || kind == RT_M_DIFFUSE_LIGHT || kind == RT_M_ISOTROPIC; }
 
-// scatter (src/material.rs:35-50, 68-83, 97-141, 167-175, 196-210). `din` = r_in.dire.
-// Returns false when the path ends here. A zero-length incoming direction (the reference would panic in
-// Vec3::unit, src/vec3.rs:285-286) also ends the path.
-RT_D bool material_scatter(const DevScene& S, const RtMaterial* M, V3 din, const HitRec& rec, rt::Rng& rng, V3& attenuation,
-                           V3& dout) {
+// scatter (src/material.rs:35-50, 68-83, 97-141, 167-175, 196-210). `din` = r_in.dire, `texv` = the material's
+// texture value at the hit. Returns false when the path ends here. A zero-length incoming direction (the
+// reference would panic in Vec3::unit, src/vec3.rs:285-286) also ends the path.
+RT_D bool material_scatter(const RtMaterial* M, V3 din, const HitRec& rec, V3 texv, rt::Rng& rng, V3& attenuation, V3& dout) {
     switch (M->kind) {
         case RT_M_LAMBERTIAN: {
             dout = rec.normal + random_unit_vector(rng);
-            attenuation = texture_value(S, M->tex, rec.u, rec.v, rec.p);
+            attenuation = texv;
             return true;
         }
         case RT_M_METAL: {
@@ -173,7 +173,7 @@ RT_D bool material_scatter(const DevScene& S, const RtMaterial* M, V3 din, const
         }
         case RT_M_ISOTROPIC: {
             dout = random_in_unit_sphere(rng);
-            attenuation = texture_value(S, M->tex, rec.u, rec.v, rec.p);
+            attenuation = texv;
             return true;
         }
         default: return false;  // RT_M_DIFFUSE_LIGHT

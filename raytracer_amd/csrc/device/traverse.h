@@ -8,6 +8,13 @@
 // of the t_max the reference threads through its recursion. Only (t, entry, side,
 // innermost wrapper) of the winning candidate are kept; the full HitRecord is
 // rebuilt once per ray in hitrecord.h.
+//
+// Shape of the walk ("while-while"): every lane first runs through box tests until
+// it stands on a non-box entry, then the wave handles those entries; lanes of a
+// wave therefore execute the box test together instead of interleaving it with
+// primitive tests. The ray a wrapper must return to on exit is not kept in
+// registers: it is re-derived from the stored world ray by replaying the parent's
+// wrapper chain (same operations, same order, hence the same bits).
 #pragma once
 #include "../../../include/rt/abi.h"
 #include "../rng.h"
@@ -50,7 +57,18 @@ struct Cand {
 // Work counters of one thread (only in the instrumented kernels).
 struct Work {
     uint32_t entries;   // stream entries fetched (32 B each)
-    uint32_t prim[9];   // primitive tests by RtNodeKind (RT_N_INNER slot counts box tests)
+    uint32_t prim[9];   // entries visited by RtNodeKind (the RT_N_INNER slot counts box tests)
+};
+
+// Where the world-space ray of a query lives in memory.
+struct RaySoA {  // path state columns
+    const double *ox, *oy, *oz, *dx, *dy, *dz;
+    uint32_t slot;
+    RT_D void load(V3& o, V3& d) const { o = v3(ox[slot], oy[slot], oz[slot]); d = v3(dx[slot], dy[slot], dz[slot]); }
+};
+struct RayAoS {  // RtRay
+    const RtRay* r;
+    RT_D void load(V3& o, V3& d) const { o = v3p(r->o); d = v3p(r->d); }
 };
 
 // ---- wrappers: ray into object space -------------------------------------------
@@ -68,36 +86,57 @@ RT_D void xf_apply(const RtXform* x, V3& o, V3& d) {
     }
 }
 
-RT_D V3 inv_dir(V3 d) { return v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }  // src/aabb.rs:17
+// The ray as seen inside wrapper xf1 - 1 (xf1 == 0: the world ray).
+template <class RS>
+RT_D void ray_at(const DevScene& S, const RS& rs, uint32_t xf1, V3& o, V3& d) {
+    rs.load(o, d);
+    if (xf1) {
+        const RtXform* x = S.xforms + (xf1 - 1u);
+        const uint32_t depth = x->depth;
+        for (uint32_t k = 0; k < depth; ++k) xf_apply(S.xforms + x->anc[k], o, d);
+    }
+}
+
+// Per-ray-segment constants of the box and sphere tests.
+struct Seg {
+    V3 o, d, invd;
+    double dd;  // d . d, the `a` of the sphere quadratic (src/hittable.rs:74)
+    RT_D void set(V3 o_, V3 d_) {
+        o = o_; d = d_;
+        invd = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);  // src/aabb.rs:17
+        dd = squared_length(d);
+    }
+};
 
 // ---- box test -------------------------------------------------------------------
 // The expressions of src/aabb.rs:17-25 on the f32 box, with tmin/tmax carried from
 // axis to axis (the reference restarts from the caller's tmin/tmax on every axis,
-// which only makes its test looser). tmin never decreases and tmax never increases
-// and neither can become NaN, so one comparison at the end equals the per-axis exit.
-RT_D bool box_hit(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 o, V3 invd, double tmin, double tmax) {
-    double t0 = ((double)lox - o.x) * invd.x;
-    double t1 = ((double)hix - o.x) * invd.x;
-    if (invd.x < 0.0) { const double s = t0; t0 = t1; t1 = s; }
-    tmin = t0 > tmin ? t0 : tmin;
-    tmax = t1 < tmax ? t1 : tmax;
-    t0 = ((double)loy - o.y) * invd.y;
-    t1 = ((double)hiy - o.y) * invd.y;
-    if (invd.y < 0.0) { const double s = t0; t0 = t1; t1 = s; }
-    tmin = t0 > tmin ? t0 : tmin;
-    tmax = t1 < tmax ? t1 : tmax;
-    t0 = ((double)loz - o.z) * invd.z;
-    t1 = ((double)hiz - o.z) * invd.z;
-    if (invd.z < 0.0) { const double s = t0; t0 = t1; t1 = s; }
-    tmin = t0 > tmin ? t0 : tmin;
-    tmax = t1 < tmax ? t1 : tmax;
-    return !(tmax <= tmin);
+// which only makes its test looser).
+//  * `if inv_d < 0 swap(t0, t1)` is done by picking lo/hi before the subtraction.
+//  * `t0 > tmin ? t0 : tmin` keeps tmin when t0 is NaN (0 * inf), which is what fmax
+//    does; likewise fmin for tmax. The two differ only when tmin or tmax themselves
+//    are NaN, where the reference's comparison `t1 <= t0` is false on every axis and
+//    the box passes: hence the final `unordered` term.
+//  * tmin never decreases and tmax never increases, so one comparison at the end
+//    equals the reference's per-axis early exit.
+RT_D bool box_hit(const uint4 na, const uint4 nb, const Seg& g, double tmin, double tmax) {
+    const float lox = __uint_as_float(na.x), loy = __uint_as_float(na.y), loz = __uint_as_float(na.z);
+    const float hix = __uint_as_float(na.w), hiy = __uint_as_float(nb.x), hiz = __uint_as_float(nb.y);
+    const bool sx = g.invd.x < 0.0, sy = g.invd.y < 0.0, sz = g.invd.z < 0.0;
+    const double t0x = ((double)(sx ? hix : lox) - g.o.x) * g.invd.x;
+    const double t1x = ((double)(sx ? lox : hix) - g.o.x) * g.invd.x;
+    const double t0y = ((double)(sy ? hiy : loy) - g.o.y) * g.invd.y;
+    const double t1y = ((double)(sy ? loy : hiy) - g.o.y) * g.invd.y;
+    const double t0z = ((double)(sz ? hiz : loz) - g.o.z) * g.invd.z;
+    const double t1z = ((double)(sz ? loz : hiz) - g.o.z) * g.invd.z;
+    const double lo = fmax(fmax(fmax(t0x, t0y), t0z), tmin);
+    const double hi = fmin(fmin(fmin(t1x, t1y), t1z), tmax);
+    return !(hi <= lo) || (tmin != tmin) || (tmax != tmax);
 }
 
 // ---- primitives -----------------------------------------------------------------
-// Sphere::hit src/hittable.rs:72-113 (strict t_min < t < t_max).
-RT_D bool sphere_roots(V3 oc, V3 d, double r, double tmin, double tmax, double& t_out) {
-    const double a = squared_length(d);
+// Sphere::hit src/hittable.rs:72-113 (strict t_min < t < t_max). `a` = d . d.
+RT_D bool sphere_roots(V3 oc, V3 d, double a, double r, double tmin, double tmax, double& t_out) {
     const double half_b = dot(oc, d);
     const double c = squared_length(oc) - r * r;
     const double discriminant = half_b * half_b - a * c;
@@ -174,117 +213,203 @@ RT_D bool triangle_hit(const RtTriangle* tr, V3 o, V3 d, double tmin, double tma
     return true;
 }
 
+// The two boundary queries of ConstantMedium::hit (src/constant_medium.rs:41-47) when the boundary is a
+// single Sphere: boundary.hit(r, -inf, inf) and boundary.hit(r, t1 + 0.0001, inf) evaluate the same quadratic,
+// so the roots are computed once and run through Sphere::hit's two range checks twice. `queries` = how many of
+// the two Sphere::hit calls the reference would have made (the second only after the first hit).
+RT_D bool sphere_boundary(const RtSphere* s, const Seg& g, double& t1, double& t2, uint32_t& queries) {
+    queries = 1u;
+    const V3 oc = g.o - v3p(s->c);
+    const double a = g.dd;
+    const double half_b = dot(oc, g.d);
+    const double c = squared_length(oc) - s->r * s->r;
+    const double discriminant = half_b * half_b - a * c;
+    if (!(discriminant > 0.0)) return false;
+    const double root = sqrt(discriminant);
+    const double ra = (-half_b - root) / a;
+    const double rb = (-half_b + root) / a;
+    if (ra < D_INF && ra > -D_INF) t1 = ra;
+    else if (rb < D_INF && rb > -D_INF) t1 = rb;
+    else return false;
+    queries = 2u;
+    const double lo = t1 + 0.0001;
+    if (ra < D_INF && ra > lo) t2 = ra;
+    else if (rb < D_INF && rb > lo) t2 = rb;
+    else return false;
+    return true;
+}
+
 // ---- the walk ---------------------------------------------------------------------
-// TOP = false is the boundary query of a ConstantMedium: same walk over the boundary's entries,
-// without media inside (the flattener rejects nested media).
-//   (bo, bd)   ray in the space the walk starts in, base_depth wrappers deep, innermost base_xf
-//   [begin,end) entries to walk
-template <bool TOP, bool COUNT>
-RT_D void closest_hit(const DevScene& S, V3 bo, V3 bd, double tm, double tmin, double tmax, uint32_t begin, uint32_t end,
-                      uint32_t base_depth, uint32_t base_xf, const RayKey& key, Cand& best, Work* work) {
-    V3 o = bo, d = bd;
-    V3 invd = inv_dir(d);
-    uint32_t cur_xf = base_xf;  // xform table index + 1, 0 = none
-    best.t = tmax;
-    best.ref = RT_MISS;
-    best.aux = 0u;
-    uint32_t i = begin;
-    while (i < end) {
-        const uint4* np = reinterpret_cast<const uint4*>(S.nodes + i);
-        const uint4 na = np[0];
-        const uint4 nb = np[1];
+// State of one closest-hit query, advanced in two kinds of steps so that a wave can keep its lanes together:
+// box_run() consumes box entries until the lane stands on a non-box entry (or the query is finished), leaf()
+// handles that one entry. One walker serves the world query and, re-entered in place, the two boundary queries
+// of a ConstantMedium (src/constant_medium.rs:41-47): on a medium entry the running result is parked, the walk
+// covers the boundary's entries [i+1, link) with the boundary query's own t range (mode 1, then mode 2), and at
+// the end of that range the medium is resolved against the parked result and the world walk resumes at `link`.
+// Wrappers inside a boundary are entered and left like anywhere else, so at the end of the range the ray is back
+// in the medium's own space. The flattener rejects media inside a boundary: one level of parking is enough.
+template <bool COUNT>
+struct Walker {
+    Seg g;
+    double tm, tmin0, tmin;
+    Cand best;
+    uint32_t i, end, cur_xf;  // cur_xf: innermost wrapper around the current entry, table index + 1, 0 = none
+    uint32_t mode;            // 0 world, 1 first boundary query, 2 second boundary query
+    double out_t, t_enter;    // parked world result, entry distance of the boundary
+    uint32_t out_ref, out_aux, med_meta, med_begin;
+    uint4 na, nb;             // the entry box_run() stopped on
+    bool done;
+
+    RT_D void init(const DevScene& S, V3 o, V3 d, double tm_, double tmin_, double tmax_) {
+        g.set(o, d);
+        tm = tm_; tmin0 = tmin_; tmin = tmin_;
+        best.t = tmax_; best.ref = RT_MISS; best.aux = 0u;
+        i = 0u; end = S.n_nodes; cur_xf = 0u; mode = 0u;
+        out_t = 0.0; t_enter = 0.0; out_ref = 0u; out_aux = 0u; med_meta = 0u; med_begin = 0u;
+        done = false;
+    }
+
+    // ConstantMedium::hit after its two boundary queries, src/constant_medium.rs:52-88
+    RT_D void resolve_medium(const DevScene& S, const RayKey& key, uint32_t meta, double t1, double t2) {
+        const RtMedium* m = S.media + (meta >> 4);
+        if (t1 < tmin) t1 = tmin;
+        if (t2 > best.t) t2 = best.t;
+        if (t1 > t2) return;
+        if (t1 < 0.0) t1 = 0.0;
+        const double ray_length = sqrt(g.dd);  // r.dire.length()
+        const double distance_inside_boundary = (t2 - t1) * ray_length;
+        rt::Rng rng;
+        rng.set_path(key.seed, key.pixel, key.sample, key.bounce, rt::RNG_MEDIUM0 + m->rng_id);
+        const double hit_distance = m->neg_inv_density * log10(rng.uniform(0.0, 1.0));  // :69
+        if (hit_distance > distance_inside_boundary) return;
+        best.t = t1 + hit_distance / ray_length;
+        best.ref = meta;
+        best.aux = cur_xf << 8;
+    }
+
+    RT_D void box_run(const DevScene& S, const RayKey& key, Work* work) {
+        for (;;) {
+            if (i >= end) {
+                if (mode == 0u) { done = true; return; }
+                // end of a boundary query; `end` is the medium's link
+                if (mode == 1u && best.ref != RT_MISS) {
+                    t_enter = best.t;
+                    tmin = best.t + 0.0001;  // src/constant_medium.rs:45
+                    best.t = D_INF;
+                    best.ref = RT_MISS;
+                    mode = 2u;
+                    i = med_begin;
+                    continue;
+                }
+                const bool inside = best.ref != RT_MISS;  // mode 2 and the second query hit
+                const double t2 = best.t;
+                best.t = out_t; best.ref = out_ref; best.aux = out_aux;
+                tmin = tmin0;
+                i = end;
+                end = S.n_nodes;
+                mode = 0u;
+                if (inside) resolve_medium(S, key, med_meta, t_enter, t2);
+                continue;
+            }
+            const uint4* np = reinterpret_cast<const uint4*>(S.nodes + i);
+            na = np[0];
+            nb = np[1];
+            if (COUNT) { work->entries++; work->prim[nb.z & 15u]++; }
+            if ((nb.z & 15u) != RT_N_INNER) return;
+            i = box_hit(na, nb, g, tmin, best.t) ? i + 1u : nb.w;
+        }
+    }
+
+    template <class RS>
+    RT_D void leaf(const DevScene& S, const RS& rs, const RayKey& key, Work* work) {
         const uint32_t meta = nb.z;
         const uint32_t kind = meta & 15u;
         const uint32_t idx = meta >> 4;
-        if (COUNT) { work->entries++; work->prim[kind]++; }
-        if (kind == RT_N_INNER) {
-            const bool pass = box_hit(__uint_as_float(na.x), __uint_as_float(na.y), __uint_as_float(na.z), __uint_as_float(na.w),
-                                      __uint_as_float(nb.x), __uint_as_float(nb.y), o, invd, tmin, best.t);
-            i = pass ? i + 1u : nb.w;
-            continue;
-        }
         switch (kind) {
             case RT_N_SPHERE: {
                 const RtSphere* s = S.spheres + idx;
                 double t;
-                if (sphere_roots(o - v3p(s->c), d, s->r, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
+                if (sphere_roots(g.o - v3p(s->c), g.d, g.dd, s->r, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
                 break;
             }
             case RT_N_MSPHERE: {
                 const RtMovingSphere* s = S.msphere + idx;
                 double t;
-                if (sphere_roots(o - msphere_center(s, tm), d, s->r, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
+                if (sphere_roots(g.o - msphere_center(s, tm), g.d, g.dd, s->r, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
                 break;
             }
             case RT_N_RECT: {
                 double t;
-                if (rect_hit(S.rects + idx, o, d, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
+                if (rect_hit(S.rects + idx, g.o, g.d, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
                 break;
             }
             case RT_N_BOX6: {
                 uint32_t side = 0u;
                 double t = best.t;
-                if (box6_hit(S.boxes + idx, o, d, tmin, t, side)) { best.t = t; best.ref = meta; best.aux = side | (cur_xf << 8); }
+                if (box6_hit(S.boxes + idx, g.o, g.d, tmin, t, side)) { best.t = t; best.ref = meta; best.aux = side | (cur_xf << 8); }
                 break;
             }
             case RT_N_TRIANGLE: {
                 double t;
-                if (triangle_hit(S.triangles + idx, o, d, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
+                if (triangle_hit(S.triangles + idx, g.o, g.d, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
                 break;
             }
             case RT_N_XF_ENTER: {
+                V3 o = g.o, d = g.d;
                 xf_apply(S.xforms + idx, o, d);
-                invd = inv_dir(d);
+                g.set(o, d);
                 cur_xf = idx + 1u;
                 break;
             }
             case RT_N_XF_EXIT: {
-                // back to the parent's space: replay the parent's chain on the base ray (same operations in
-                // the same order as on the way in, hence the same bits)
                 const RtXform* x = S.xforms + idx;
                 const uint32_t depth = x->depth;
-                o = bo; d = bd;
-                for (uint32_t k = base_depth; k + 1u < depth; ++k) xf_apply(S.xforms + x->anc[k], o, d);
-                invd = inv_dir(d);
-                cur_xf = (depth - 1u > base_depth) ? x->anc[depth - 2u] + 1u : base_xf;
+                cur_xf = depth > 1u ? x->anc[depth - 2u] + 1u : 0u;
+                V3 o, d;
+                ray_at(S, rs, cur_xf, o, d);
+                g.set(o, d);
                 break;
             }
-            case RT_N_MEDIUM: {
-                if (TOP) {
-                    // ConstantMedium::hit src/constant_medium.rs:34-89
-                    const RtMedium* m = S.media + idx;
-                    const uint32_t depth_here = cur_xf ? S.xforms[cur_xf - 1u].depth : 0u;
-                    Cand c1, c2;
-                    closest_hit<false, COUNT>(S, o, d, tm, -D_INF, D_INF, i + 1u, nb.w, depth_here, cur_xf, key, c1, work);
-                    if (c1.ref != RT_MISS) {
-                        closest_hit<false, COUNT>(S, o, d, tm, c1.t + 0.0001, D_INF, i + 1u, nb.w, depth_here, cur_xf, key, c2, work);
-                        if (c2.ref != RT_MISS) {
-                            double t1 = c1.t, t2 = c2.t;
-                            if (t1 < tmin) t1 = tmin;
-                            if (t2 > best.t) t2 = best.t;
-                            if (!(t1 > t2)) {
-                                if (t1 < 0.0) t1 = 0.0;
-                                const double ray_length = length(d);
-                                const double distance_inside_boundary = (t2 - t1) * ray_length;
-                                rt::Rng rng;
-                                rng.set_path(key.seed, key.pixel, key.sample, key.bounce, rt::RNG_MEDIUM0 + m->rng_id);
-                                const double hit_distance = m->neg_inv_density * log10(rng.uniform(0.0, 1.0));  // :69
-                                if (!(hit_distance > distance_inside_boundary)) {
-                                    best.t = t1 + hit_distance / ray_length;
-                                    best.ref = meta;
-                                    best.aux = cur_xf << 8;
-                                }
-                            }
-                        }
-                    }
+            default: {  // RT_N_MEDIUM, ConstantMedium::hit src/constant_medium.rs:34-89 (mode is 0 here)
+                const uint32_t first = S.nodes[i + 1u].meta;
+                if (nb.w == i + 2u && (first & 15u) == RT_N_SPHERE) {
+                    // boundary is one sphere: both queries from one quadratic
+                    double t1 = 0.0, t2 = 0.0;
+                    uint32_t queries;
+                    const bool inside = sphere_boundary(S.spheres + (first >> 4), g, t1, t2, queries);
+                    if (COUNT) { work->entries += queries; work->prim[RT_N_SPHERE] += queries; }
+                    if (inside) resolve_medium(S, key, meta, t1, t2);
+                    i = nb.w;
+                } else {
+                    out_t = best.t; out_ref = best.ref; out_aux = best.aux;
+                    med_meta = meta;
+                    med_begin = i + 1u;
+                    best.t = D_INF;  // boundary.hit(r, -inf, inf), src/constant_medium.rs:41
+                    best.ref = RT_MISS;
+                    tmin = -D_INF;
+                    mode = 1u;
+                    end = nb.w;
+                    i = i + 1u;
                 }
-                i = nb.w;
-                continue;
+                return;
             }
-            default: break;
         }
         ++i;
     }
+};
+
+// One query start to finish (the stand-alone trace kernels).
+template <bool COUNT, class RS>
+RT_D void closest_hit(const DevScene& S, const RS& rs, V3 o0, V3 d0, double tm, double tmin0, double tmax0, const RayKey& key,
+                      Cand& best, Work* work) {
+    Walker<COUNT> w;
+    w.init(S, o0, d0, tm, tmin0, tmax0);
+    for (;;) {
+        w.box_run(S, key, work);
+        if (w.done) break;
+        w.leaf(S, rs, key, work);
+    }
+    best = w.best;
 }
 
 }  // namespace rtd

@@ -34,7 +34,7 @@ struct Workspace {
     char* base = nullptr;  // one allocation: 14 f64 columns, hit_ref, hit_aux, two queues
     PathState P{};
     uint32_t* queue[2] = {nullptr, nullptr};
-    uint32_t* counts = nullptr;              // [2] queue lengths
+    uint32_t* counts = nullptr;              // [0], [1] queue lengths, [2] ray cursor of the extend launch, [3] cursor of rt_trace_*
     unsigned long long* ray_total = nullptr; // [1] + work counters [kWorkWords]
     std::vector<hipEvent_t> events;
 };
@@ -47,6 +47,7 @@ struct RtScene {
     std::vector<void*> allocs;
     Workspace ws;
     uint32_t n_cus = 256;
+    uint32_t grid_extend = 256;  // resident blocks of the persistent closest-hit kernels
 };
 
 namespace {
@@ -154,6 +155,12 @@ uint32_t grid_for(const RtScene* s, uint64_t n) {
     return (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
 }
 
+// The trace kernels are persistent: never more blocks than can be resident, fewer when there are few rays.
+uint32_t trace_grid(const RtScene* s, uint64_t n) {
+    const uint64_t want = (n + 8 * (rtd::BLOCK / 64) - 1) / (8 * (rtd::BLOCK / 64));
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, s->grid_extend));
+}
+
 void free_workspace(Workspace& w) {
     if (w.base) (void)hipFree(w.base);
     if (w.counts) (void)hipFree(w.counts);
@@ -165,7 +172,7 @@ void free_workspace(Workspace& w) {
 int ensure_workspace(RtScene* s, uint64_t n_slots) {
     Workspace& w = s->ws;
     if (!w.counts) {
-        HIP_TRY(hipMalloc((void**)&w.counts, 2 * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&w.counts, 4 * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&w.ray_total, (1 + kWorkWords) * sizeof(unsigned long long)));
     }
     if (w.cap_slots >= n_slots) return RT_OK;
@@ -224,6 +231,7 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     }
     size_t ev = 0;
     HIP_TRY(hipMemsetAsync(w.ray_total, 0, (1 + kWorkWords) * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), stream));
     if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
     for (uint32_t b = 0; b < n_batches; ++b) {
         const uint32_t s0 = p->sample_begin + b * spb;
@@ -235,17 +243,16 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         for (uint32_t bounce = 0; bounce < p->max_depth; ++bounce) {
             const int cur = (int)(bounce & 1u), nxt = cur ^ 1;
             const uint32_t* q = bounce == 0 ? nullptr : w.queue[cur];
-            HIP_TRY(hipMemsetAsync(w.counts + nxt, 0, sizeof(uint32_t), stream));
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
             if (work)
-                hipLaunchKernelGGL(rtd::k_extend<true>, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts + cur, bounce,
-                                   w.ray_total + 1);
+                hipLaunchKernelGGL(rtd::k_extend<true>, dim3(s->grid_extend), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts, (uint32_t)cur,
+                                   bounce, w.ray_total + 1);
             else
-                hipLaunchKernelGGL(rtd::k_extend<false>, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts + cur, bounce,
-                                   (unsigned long long*)nullptr);
+                hipLaunchKernelGGL(rtd::k_extend<false>, dim3(s->grid_extend), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts, (uint32_t)cur,
+                                   bounce, (unsigned long long*)nullptr);
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
-            hipLaunchKernelGGL(rtd::k_shade, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts + cur, w.queue[nxt],
-                               w.counts + nxt, bounce, w.ray_total);
+            hipLaunchKernelGGL(rtd::k_shade, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts, (uint32_t)cur, w.queue[nxt],
+                               bounce, w.ray_total);
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
         }
         hipLaunchKernelGGL(rtd::k_accumulate, dim3(grid_for(s, npix)), dim3(rtd::BLOCK), 0, stream, C, w.P, accum_dev);
@@ -301,6 +308,9 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) { rc = rt::set_error(RT_E_DEVICE, "hipGetDeviceProperties failed"); break; }
         s->n_cus = (uint32_t)std::max(1, prop.multiProcessorCount);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false>, rtd::BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        s->grid_extend = s->n_cus * (uint32_t)per_cu;
         if ((rc = upload(s, d->nodes, d->n_nodes, &s->S.nodes))) break;
         if ((rc = upload(s, d->spheres, d->n_spheres, &s->S.spheres))) break;
         if ((rc = upload(s, d->msphere, d->n_msphere, &s->S.msphere))) break;
@@ -333,8 +343,11 @@ int rt_trace_closest_device(RtScene* s, const RtRay* rays_dev, uint64_t n, uint6
     if (!s || (n && (!rays_dev || !out_dev))) return rt::set_error(RT_E_INVALID, "null argument");
     if (n == 0) return RT_OK;
     if (int rc = bind_device(s)) return rc;
-    hipLaunchKernelGGL((rtd::k_trace<false, false>), dim3(grid_for(s, n)), dim3(rtd::BLOCK), 0, (hipStream_t)stream, s->S, rays_dev, n,
-                       seed, out_dev, (RtHitRecord*)nullptr, (unsigned long long*)nullptr);
+    if (n >= (1ull << 32)) return rt::set_error(RT_E_INVALID, "too many rays in one call");
+    if (int rc = ensure_workspace(s, 0)) return rc;
+    HIP_TRY(hipMemsetAsync(s->ws.counts + 3, 0, sizeof(uint32_t), (hipStream_t)stream));
+    hipLaunchKernelGGL((rtd::k_trace<false, false>), dim3(trace_grid(s, n)), dim3(rtd::BLOCK), 0, (hipStream_t)stream, s->S, rays_dev, n,
+                       seed, out_dev, (RtHitRecord*)nullptr, s->ws.counts + 3, (unsigned long long*)nullptr);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -374,14 +387,18 @@ int trace_host(RtScene* s, const RtRay* rays, uint64_t n, uint64_t seed, RtHit* 
         }
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
-        const dim3 grid(grid_for(s, n)), block(rtd::BLOCK);
+        if (n >= (1ull << 32)) return rt::set_error(RT_E_INVALID, "too many rays in one call");
+        if (int rc2 = ensure_workspace(s, 0)) return rc2;
+        uint32_t* cursor = s->ws.counts + 3;
+        HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t), nullptr));
+        const dim3 grid(trace_grid(s, n)), block(rtd::BLOCK);
         HIP_TRY(hipEventRecord(e0, nullptr));
         if (recs) {
-            if (work) hipLaunchKernelGGL((rtd::k_trace<true, true>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)nullptr, (RtHitRecord*)d_out, d_work);
-            else hipLaunchKernelGGL((rtd::k_trace<true, false>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)nullptr, (RtHitRecord*)d_out, d_work);
+            if (work) hipLaunchKernelGGL((rtd::k_trace<true, true>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)nullptr, (RtHitRecord*)d_out, cursor, d_work);
+            else hipLaunchKernelGGL((rtd::k_trace<true, false>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)nullptr, (RtHitRecord*)d_out, cursor, d_work);
         } else {
-            if (work) hipLaunchKernelGGL((rtd::k_trace<false, true>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)d_out, (RtHitRecord*)nullptr, d_work);
-            else hipLaunchKernelGGL((rtd::k_trace<false, false>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)d_out, (RtHitRecord*)nullptr, d_work);
+            if (work) hipLaunchKernelGGL((rtd::k_trace<false, true>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)d_out, (RtHitRecord*)nullptr, cursor, d_work);
+            else hipLaunchKernelGGL((rtd::k_trace<false, false>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)d_out, (RtHitRecord*)nullptr, cursor, d_work);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e1, nullptr));

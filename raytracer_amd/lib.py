@@ -11,7 +11,7 @@ from . import abi
 from .hostapi import SceneApi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")  # RT_HIP_LIB: developer override for A/B builds
 
 ABI_SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_trace_closest",
