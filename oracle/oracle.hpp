@@ -23,8 +23,10 @@
 //  * Vec3::unit() of a zero vector panics in the reference (src/vec3.rs:285-286);
 //    here scatter treats such a path as absorbed.
 //  * aabb_mode TIGHT (what the GPU runs) replaces the reference's three
-//    independent 1-D overlap tests (src/aabb.rs:15-30) by the carried slab test
-//    on boxes rounded outward to f32; REFERENCE mode keeps src/aabb.rs as is.
+//    independent 1-D overlap tests (src/aabb.rs:15-30) by a carried slab test
+//    on boxes rounded outward to f32 (FBox::hit); REFERENCE mode keeps
+//    src/aabb.rs as is. Both give the same closest hit whenever boxes bound
+//    their contents.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -213,18 +215,22 @@ struct FBox {
             }
         return f;
     }
-    // Carried slab test, otherwise the same expressions as src/aabb.rs:17-25.
+    // The "tight" rule shared bit for bit with the HIP kernels: near/far plane picked by the sign of 1/d (the
+    // reference's swap, src/aabb.rs:20-22), t = fma(plane, 1/d, -(o * 1/d)) per plane, the interval carried across
+    // the three axes with NaN terms ignored, pass unless hi <= lo; a NaN tmin or tmax passes (src/aabb.rs:23-25).
     bool hit(const Ray& r, double tmin, double tmax) const {
+        if (tmin != tmin || tmax != tmax) return true;
+        double lo_t = tmin, hi_t = tmax;
         for (int a = 0; a < 3; ++a) {
-            double inv_d = 1.0 / r.dire[a];
-            double t0 = ((double)lo[a] - r.orig[a]) * inv_d;
-            double t1 = ((double)hi[a] - r.orig[a]) * inv_d;
-            if (inv_d < 0.0) std::swap(t0, t1);
-            tmin = t0 > tmin ? t0 : tmin;
-            tmax = t1 < tmax ? t1 : tmax;
-            if (tmax <= tmin) return false;
+            const double inv_d = 1.0 / r.dire[a];
+            const double noi = -(r.orig[a] * inv_d);
+            const bool neg = inv_d < 0.0;
+            const double t0 = std::fma((double)(neg ? hi[a] : lo[a]), inv_d, noi);
+            const double t1 = std::fma((double)(neg ? lo[a] : hi[a]), inv_d, noi);
+            lo_t = std::fmax(t0, lo_t);
+            hi_t = std::fmin(t1, hi_t);
         }
-        return true;
+        return !(hi_t <= lo_t);
     }
 };
 

@@ -1,28 +1,64 @@
 // gfx950 kernels of the wavefront path tracer: generate / extend / shade / accumulate /
 // resolve, plus the stand-alone closest-hit kernels behind rt_trace_*.
 //
-// One path sample per lane. Path state lives in HBM as structure-of-arrays f64
-// columns indexed by path slot (slot = local_sample * n_pixels + pixel), so lanes
-// of a wave touch consecutive addresses while the queue is still dense. Every
-// bounce is two launches over the queue of live slots:
-//   extend: closest hit of the slot's ray  -> hit columns            (src/color.rs:41)
-//   shade : rebuild the HitRecord, add emitted light, scatter, write the next
-//           ray and throughput, append survivors to the next queue    (src/color.rs:50-62)
-// Survivors are compacted with one ballot and one atomic per wave. No kernel needs
-// the queue length on the host: launches are fixed-size grid-stride loops that read
-// the length from device memory.
+// One path sample per lane. The live paths of a bounce are a dense array of 96-byte ray records
+// (origin, direction, time, slot, throughput); every bounce is two launches over it:
+//   extend: closest hit of record i            -> hit[i]                        (src/color.rs:41)
+//   shade : rebuild the HitRecord, add emitted light, scatter; survivors are written, compacted
+//           with one ballot and one atomic per wave, into the other record array  (src/color.rs:50-62)
+// so both kernels stream consecutive records instead of chasing an index queue, and a path costs one
+// record read per kernel. Radiance gathered by a path lives in per-slot columns (slot = local_sample *
+// n_pixels + pixel) that are touched only when light is added (miss or emitter) and summed per pixel by
+// accumulate. No kernel needs the array length on the host: launches are fixed-size loops that read the
+// length from device memory.
 #pragma once
 #include "shade.h"
 
 namespace rtd {
 
-struct PathState {
-    double *ox, *oy, *oz, *dx, *dy, *dz, *tm;  // current ray (src/ray.rs:3-7)
-    double *tr, *tg, *tb;                      // throughput: product of attenuations so far
-    double *lr, *lg, *lb;                      // radiance gathered so far
-    double* hit_t;                             // extend -> shade
-    uint32_t *hit_ref, *hit_aux;
+struct alignas(32) RayRec {     // 96 bytes; extend reads the first 64
+    double o[3], d[3], tm;      // the ray handed to world.hit (src/ray.rs:3-7)
+    uint32_t slot, pad0;
+    double T[3];                // throughput: product of attenuations so far
+    double pad1;
 };
+struct alignas(16) HitSlot {    // extend -> shade, indexed like the records
+    double t;
+    uint32_t ref, aux;
+};
+
+struct PathState {
+    RayRec* rec[2];             // records of the current / next bounce
+    HitSlot* hit;
+    double *lr, *lg, *lb;       // radiance gathered so far, per slot
+};
+
+// 16-byte loads/stores of a record (global_load_dwordx4 / global_store_dwordx4)
+RT_D void load_ray64(const RayRec* r, V3& o, V3& d, double& tm, uint32_t& slot) {
+    const double2* p = reinterpret_cast<const double2*>(r);
+    const double2 a = p[0], b = p[1], c = p[2];
+    const uint4 e = reinterpret_cast<const uint4*>(r)[3];
+    o = v3(a.x, a.y, b.x);
+    d = v3(b.y, c.x, c.y);
+    tm = __hiloint2double((int)e.y, (int)e.x);
+    slot = e.z;
+}
+RT_D void load_throughput(const RayRec* r, V3& T) {
+    const double2* p = reinterpret_cast<const double2*>(r);
+    const double2 a = p[4], b = p[5];
+    T = v3(a.x, a.y, b.x);
+}
+RT_D void store_ray(RayRec* r, V3 o, V3 d, double tm, uint32_t slot, V3 T) {
+    double2* p = reinterpret_cast<double2*>(r);
+    p[0] = make_double2(o.x, o.y);
+    p[1] = make_double2(o.z, d.x);
+    p[2] = make_double2(d.y, d.z);
+    uint4 e;
+    e.x = (uint32_t)__double2loint(tm); e.y = (uint32_t)__double2hiint(tm); e.z = slot; e.w = 0u;
+    reinterpret_cast<uint4*>(r)[3] = e;
+    p[4] = make_double2(T.x, T.y);
+    p[5] = make_double2(T.z, 0.0);
+}
 
 struct RenderConst {
     RtCamera cam;
@@ -54,7 +90,10 @@ constexpr int BLOCK = 256;
 // primitive tests.
 //
 // IO supplies the pool: n(), fetch(index, ...) and store(index, ...).
-constexpr uint32_t REFILL_LANES = 16;  // refill when at least this many lanes are idle
+#ifndef RT_REFILL_LANES
+#define RT_REFILL_LANES 32
+#endif
+constexpr uint32_t REFILL_LANES = RT_REFILL_LANES;  // refill when at least this many lanes are idle
 
 template <bool COUNT, class IO>
 RT_D void extend_pool(const DevScene& S, IO& io, uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
@@ -71,14 +110,21 @@ RT_D void extend_pool(const DevScene& S, IO& io, uint32_t* __restrict__ cursor, 
     w.done = true;
     typename IO::Ray ray;
     uint32_t index = 0u;
-    bool busy = false;
-    bool exhausted = false;  // wave-uniform
+    bool busy = false;      // the lane holds an unfinished query
+    bool pending = false;   // the lane holds a finished query whose result is not stored yet
+    bool exhausted = false; // wave-uniform: the pool has no rays left
     for (;;) {
         const unsigned long long act = __ballot(busy);
         const uint32_t n_act = (uint32_t)__popcll(act);
-        if (!exhausted) {
-            const uint32_t room = max_active > n_act ? max_active - n_act : 0u;
-            if (room >= refill_at || (n_act == 0u && room > 0u)) {
+        const uint32_t room = max_active > n_act ? max_active - n_act : 0u;
+        // Results are stored and new rays fetched at the same moment, so that the wave meets global-memory
+        // latency once per refill instead of at every step in which some lane finishes.
+        if ((!exhausted && (room >= refill_at || n_act == 0u)) || (exhausted && n_act == 0u)) {
+            if (pending) {
+                io.store(S, index, ray, w.best);
+                pending = false;
+            }
+            if (!exhausted && room > 0u) {
                 const uint32_t my_rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
                 uint32_t base = 0u;
                 if (lane == 0u) base = atomicAdd(cursor, room);
@@ -100,8 +146,8 @@ RT_D void extend_pool(const DevScene& S, IO& io, uint32_t* __restrict__ cursor, 
             w.box_run(S, ray.key, &work);
             if (!w.done) w.leaf(S, ray.rs, ray.key, &work);
             if (w.done) {
-                io.store(S, index, ray, w.best);
                 busy = false;
+                pending = true;
             }
         }
     }
@@ -181,66 +227,69 @@ __global__ void __launch_bounds__(BLOCK) k_generate(RenderConst C, PathState P) 
         V3 o, d;
         double tm;
         camera_ray(C.cam, C.seed, C.width, C.height, x, y, pix, sample, o, d, tm);
-        P.ox[slot] = o.x; P.oy[slot] = o.y; P.oz[slot] = o.z;
-        P.dx[slot] = d.x; P.dy[slot] = d.y; P.dz[slot] = d.z;
-        P.tm[slot] = tm;
-        P.tr[slot] = 1.0; P.tg[slot] = 1.0; P.tb[slot] = 1.0;
+        store_ray(P.rec[0] + slot, o, d, tm, slot, v3(1.0, 1.0, 1.0));
         P.lr[slot] = 0.0; P.lg[slot] = 0.0; P.lb[slot] = 0.0;
     }
 }
 
 // ---- extend ------------------------------------------------------------------------------
-// queue == nullptr: the identity queue of bounce 0 (every slot of the batch is live).
+struct RayRecRef {  // where a query's world ray lives (re-read when a wrapper is left)
+    const RayRec* r;
+    RT_D void load(V3& o, V3& d) const {
+        double tm; uint32_t slot;
+        load_ray64(r, o, d, tm, slot);
+    }
+};
 struct ExtendIO {
-    RenderConst C;
-    PathState P;
-    const uint32_t* queue;
-    uint32_t count, bounce;
+    const RayRec* recs;
+    HitSlot* hits;
+    uint64_t seed;
+    uint32_t npix, sample0, count, bounce;
     struct Ray {
         V3 o, d;
         double tm;
         static constexpr double tmin = 0.0001;  // src/color.rs:41
         static constexpr double tmax = D_INF;
         RayKey key;
-        RaySoA rs;
+        RayRecRef rs;
     };
     RT_D uint32_t n() const { return count; }
     RT_D void fetch(uint32_t i, Ray& r) const {
-        const uint32_t slot = queue ? queue[i] : i;
-        r.rs.ox = P.ox; r.rs.oy = P.oy; r.rs.oz = P.oz; r.rs.dx = P.dx; r.rs.dy = P.dy; r.rs.dz = P.dz; r.rs.slot = slot;
-        r.rs.load(r.o, r.d);
-        r.tm = P.tm[slot];
-        r.key.seed = C.seed; r.key.pixel = slot % C.npix; r.key.sample = C.sample0 + slot / C.npix; r.key.bounce = bounce;
+        r.rs.r = recs + i;
+        uint32_t slot;
+        load_ray64(recs + i, r.o, r.d, r.tm, slot);
+        r.key.seed = seed; r.key.pixel = slot % npix; r.key.sample = sample0 + slot / npix; r.key.bounce = bounce;
     }
-    RT_D void store(const DevScene&, uint32_t, const Ray& r, const Cand& best) const {
-        const uint32_t slot = r.rs.slot;
-        P.hit_t[slot] = best.t;
-        P.hit_ref[slot] = best.ref;
-        P.hit_aux[slot] = best.aux;
+    RT_D void store(const DevScene&, uint32_t i, const Ray&, const Cand& best) const {
+        uint4 h;
+        h.x = (uint32_t)__double2loint(best.t); h.y = (uint32_t)__double2hiint(best.t); h.z = best.ref; h.w = best.aux;
+        *reinterpret_cast<uint4*>(hits + i) = h;
     }
 };
 
-// counts[0], counts[1]: lengths of the two queues; counts[2]: the ray cursor of this launch (zero on entry,
-// reset by the shade launch that follows).
+// counts[0], counts[1]: lengths of the two record arrays; counts[2]: the ray cursor of this launch (zero on
+// entry, reset by the shade launch that follows).
 template <bool COUNT>
-__global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DevScene S, RenderConst C, PathState P, const uint32_t* __restrict__ queue,
-                                                  uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
-                                                  unsigned long long* __restrict__ work_out) {
+__global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DevScene S, RenderConst C, PathState P, uint32_t* __restrict__ counts,
+                                                                   uint32_t cur, uint32_t bounce,
+                                                                   unsigned long long* __restrict__ work_out) {
     ExtendIO io;
-    io.C = C; io.P = P; io.queue = queue; io.bounce = bounce;
-    io.count = queue ? counts[cur] : C.n_slots;
-    if (blockIdx.x == 0 && threadIdx.x == 0) counts[cur ^ 1u] = 0u;  // the queue the following shade launch appends to
+    io.recs = P.rec[cur]; io.hits = P.hit; io.seed = C.seed; io.npix = C.npix; io.sample0 = C.sample0; io.bounce = bounce;
+    io.count = bounce == 0u ? C.n_slots : counts[cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[cur ^ 1u] = 0u;  // the array the following shade launch appends to
     extend_pool<COUNT>(S, io, counts + 2, work_out);
 }
 
 // ---- shade ---------------------------------------------------------------------------------
 // The body of ray_color after world.hit (src/color.rs:42-62), unrolled from recursion into
-// L += T * emitted; T *= attenuation. Survivors go to next_queue.
-__global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DevScene S, RenderConst C, PathState P, const uint32_t* __restrict__ queue,
-                                                 uint32_t* __restrict__ counts, uint32_t cur, uint32_t* __restrict__ next_queue,
-                                                 uint32_t bounce, unsigned long long* __restrict__ ray_total) {
-    const uint32_t n = queue ? counts[cur] : C.n_slots;
+// L += T * emitted; T *= attenuation. Survivors go to the other record array.
+__global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DevScene S, RenderConst C, PathState P, uint32_t* __restrict__ counts,
+                                                                 uint32_t cur, uint32_t bounce,
+                                                                 unsigned long long* __restrict__ ray_total) {
+    const uint32_t n = bounce == 0u ? C.n_slots : counts[cur];
     uint32_t* next_count = counts + (cur ^ 1u);
+    const RayRec* recs = P.rec[cur];
+    RayRec* next = P.rec[cur ^ 1u];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(ray_total, (unsigned long long)n);
         counts[2] = 0u;  // ray cursor of the next extend launch
@@ -250,20 +299,20 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DevScene S, Ren
     const uint32_t n_round = (n + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += stride) {
         bool alive = false;
+        V3 no = v3(0.0, 0.0, 0.0), nd = no, T = no;
+        double tm = 0.0;
         uint32_t slot = 0u;
         if (i < n) {
-            slot = queue ? queue[i] : i;
-            const uint32_t ref = P.hit_ref[slot];
-            V3 T = v3(P.tr[slot], P.tg[slot], P.tb[slot]);
-            V3 L = v3(P.lr[slot], P.lg[slot], P.lb[slot]);
-            if (ref == RT_MISS) {
-                L = L + elemul(T, v3p(C.bg));  // src/color.rs:41-43
+            V3 o, d;
+            load_ray64(recs + i, o, d, tm, slot);
+            load_throughput(recs + i, T);
+            const uint4 h = *reinterpret_cast<const uint4*>(P.hit + i);
+            Cand best;
+            best.t = __hiloint2double((int)h.y, (int)h.x); best.ref = h.z; best.aux = h.w;
+            if (best.ref == RT_MISS) {
+                const V3 add = elemul(T, v3p(C.bg));  // src/color.rs:41-43
+                P.lr[slot] += add.x; P.lg[slot] += add.y; P.lb[slot] += add.z;
             } else {
-                Cand best;
-                best.t = P.hit_t[slot]; best.ref = ref; best.aux = P.hit_aux[slot];
-                const V3 o = v3(P.ox[slot], P.oy[slot], P.oz[slot]);
-                const V3 d = v3(P.dx[slot], P.dy[slot], P.dz[slot]);
-                const double tm = P.tm[slot];
                 const RtMaterial* M = S.materials + hit_material(S, best);
                 const uint32_t mkind = M->kind;
                 const bool textured = material_has_texture(mkind);
@@ -272,30 +321,30 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DevScene S, Ren
                 build_hit_record(S, o, d, tm, best, rec, want_uv);
                 V3 texv = v3(0.0, 0.0, 0.0);
                 if (textured) texv = texture_value(S, M->tex, rec.u, rec.v, rec.p);
-                if (mkind == RT_M_DIFFUSE_LIGHT) L = L + elemul(T, texv);  // emitted, :50 (zero for every other material)
+                if (mkind == RT_M_DIFFUSE_LIGHT) {  // emitted, :50 (zero for every other material)
+                    const V3 add = elemul(T, texv);
+                    P.lr[slot] += add.x; P.lg[slot] += add.y; P.lb[slot] += add.z;
+                }
                 rt::Rng rng;
                 rng.set_path(C.seed, slot % C.npix, C.sample0 + slot / C.npix, bounce, rt::RNG_SCATTER);
                 V3 attenuation = v3(0.0, 0.0, 0.0), dout = v3(1.0, 1.0, 1.0);
                 if (material_scatter(M, d, rec, texv, rng, attenuation, dout)) {  // :52-57
                     T = elemul(T, attenuation);
                     alive = bounce + 1u < C.max_depth;  // ray_color(depth - 1) returns black at depth 0 (:37-39)
-                    if (alive) {
-                        P.ox[slot] = rec.p.x; P.oy[slot] = rec.p.y; P.oz[slot] = rec.p.z;
-                        P.dx[slot] = dout.x; P.dy[slot] = dout.y; P.dz[slot] = dout.z;
-                        P.tr[slot] = T.x; P.tg[slot] = T.y; P.tb[slot] = T.z;
-                    }
+                    no = rec.p;
+                    nd = dout;
                 }
             }
-            P.lr[slot] = L.x; P.lg[slot] = L.y; P.lb[slot] = L.z;
         }
-        // compaction: one atomic per wave
+        // compaction: one atomic per wave, survivors of a wave land in consecutive records
         const unsigned long long mask = __ballot(alive);
         if (mask) {
             const uint32_t lane = threadIdx.x & 63u;
+            const int leader = __ffsll((long long)mask) - 1;
             uint32_t base = 0u;
-            if (lane == (uint32_t)__ffsll((long long)mask) - 1u) base = atomicAdd(next_count, (uint32_t)__popcll(mask));
-            base = __shfl(base, __ffsll((long long)mask) - 1, 64);
-            if (alive) next_queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+            if ((int)lane == leader) base = atomicAdd(next_count, (uint32_t)__popcll(mask));
+            base = __shfl(base, leader, 64);
+            if (alive) store_ray(next + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), no, nd, tm, slot, T);
         }
     }
 }

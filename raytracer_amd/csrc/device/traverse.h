@@ -100,47 +100,84 @@ RT_D void ray_at(const DevScene& S, const RS& rs, uint32_t xf1, V3& o, V3& d) {
 // Per-ray-segment constants of the box and sphere tests.
 struct Seg {
     V3 o, d, invd;
+    V3 noi;     // -(o * invd), the constant term of the box test
     double dd;  // d . d, the `a` of the sphere quadratic (src/hittable.rs:74)
     RT_D void set(V3 o_, V3 d_) {
         o = o_; d = d_;
         invd = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);  // src/aabb.rs:17
+        noi = v3(-(o.x * invd.x), -(o.y * invd.y), -(o.z * invd.z));
+        dd = squared_length(d);
+    }
+    // Translate::hit moves the origin only (src/hittable.rs:278-282): direction-derived terms stay.
+    RT_D void set_origin(V3 o_) {
+        o = o_;
+        noi = v3(-(o.x * invd.x), -(o.y * invd.y), -(o.z * invd.z));
+    }
+    // RotateY::hit changes x and z of origin and direction (src/hittable.rs:358-362): the y terms stay.
+    RT_D void set_xz(double ox, double oz, double dx, double dz) {
+        o.x = ox; o.z = oz; d.x = dx; d.z = dz;
+        invd.x = 1.0 / dx; invd.z = 1.0 / dz;
+        noi.x = -(ox * invd.x); noi.z = -(oz * invd.z);
         dd = squared_length(d);
     }
 };
 
 // ---- box test -------------------------------------------------------------------
-// The expressions of src/aabb.rs:17-25 on the f32 box, with tmin/tmax carried from
-// axis to axis (the reference restarts from the caller's tmin/tmax on every axis,
-// which only makes its test looser).
-//  * `if inv_d < 0 swap(t0, t1)` is done by picking lo/hi before the subtraction.
-//  * `t0 > tmin ? t0 : tmin` keeps tmin when t0 is NaN (0 * inf), which is what fmax
-//    does; likewise fmin for tmax. The two differ only when tmin or tmax themselves
-//    are NaN, where the reference's comparison `t1 <= t0` is false on every axis and
-//    the box passes: hence the final `unordered` term.
-//  * tmin never decreases and tmax never increases, so one comparison at the end
-//    equals the reference's per-axis early exit.
+// Carried-interval slab test on the f32 box of a BVHNode. The reference's AABB::hit (src/aabb.rs:15-30)
+// restarts from the caller's tmin/tmax on every axis, which only makes it looser; any conservative test gives
+// the same closest hit as long as boxes bound their contents. The rule, shared bit for bit with the CPU
+// oracle's "tight" mode:
+//     near/far = the box planes picked by the sign of 1/d (the reference's swap, src/aabb.rs:20-22)
+//     t0 = fma(near, 1/d, -(o * 1/d)),  t1 = fma(far, 1/d, -(o * 1/d))      per axis
+//     lo = max(t0x, t0y, t0z, tmin),  hi = min(t1x, t1y, t1z, tmax),  NaN terms ignored (fmax/fmin)
+//     pass unless hi <= lo; a NaN tmin or tmax passes (as src/aabb.rs:23-25 would)
 RT_D bool box_hit(const uint4 na, const uint4 nb, const Seg& g, double tmin, double tmax) {
     const float lox = __uint_as_float(na.x), loy = __uint_as_float(na.y), loz = __uint_as_float(na.z);
     const float hix = __uint_as_float(na.w), hiy = __uint_as_float(nb.x), hiz = __uint_as_float(nb.y);
     const bool sx = g.invd.x < 0.0, sy = g.invd.y < 0.0, sz = g.invd.z < 0.0;
-    const double t0x = ((double)(sx ? hix : lox) - g.o.x) * g.invd.x;
-    const double t1x = ((double)(sx ? lox : hix) - g.o.x) * g.invd.x;
-    const double t0y = ((double)(sy ? hiy : loy) - g.o.y) * g.invd.y;
-    const double t1y = ((double)(sy ? loy : hiy) - g.o.y) * g.invd.y;
-    const double t0z = ((double)(sz ? hiz : loz) - g.o.z) * g.invd.z;
-    const double t1z = ((double)(sz ? loz : hiz) - g.o.z) * g.invd.z;
+    const double t0x = fma((double)(sx ? hix : lox), g.invd.x, g.noi.x);
+    const double t1x = fma((double)(sx ? lox : hix), g.invd.x, g.noi.x);
+    const double t0y = fma((double)(sy ? hiy : loy), g.invd.y, g.noi.y);
+    const double t1y = fma((double)(sy ? loy : hiy), g.invd.y, g.noi.y);
+    const double t0z = fma((double)(sz ? hiz : loz), g.invd.z, g.noi.z);
+    const double t1z = fma((double)(sz ? loz : hiz), g.invd.z, g.noi.z);
     const double lo = fmax(fmax(fmax(t0x, t0y), t0z), tmin);
     const double hi = fmin(fmin(fmin(t1x, t1y), t1z), tmax);
     return !(hi <= lo) || (tmin != tmin) || (tmax != tmax);
 }
 
 // ---- primitives -----------------------------------------------------------------
-// Sphere::hit src/hittable.rs:72-113 (strict t_min < t < t_max). `a` = d . d.
+// Every primitive test below evaluates the reference's expressions exactly when it may succeed. In front of
+// the expensive part (division, f64 sqrt) sits a screen that proves failure from cheaper approximations with
+// error margins orders of magnitude above their rounding error; it can only say "cannot hit", NaN or infinite
+// intermediates make its comparisons false and fall through to the exact test.
+#ifndef RT_SCREEN_SPHERE
+#define RT_SCREEN_SPHERE 1
+#endif
+#ifndef RT_SCREEN_RECT
+#define RT_SCREEN_RECT 1
+#endif
+constexpr double SCREEN_T = 0x1.0p-46;   // relative margin on an approximate quotient (its error is < 2^-50)
+constexpr double SCREEN_P = 0x1.0p-44;   // relative margin on o + t*d built from it
+constexpr double SCREEN_ABS = 1e-290;    // covers the subnormal range
+
+// Sphere::hit src/hittable.rs:72-113 (strict t_min < t < t_max). `a` = d . d > 0.
 RT_D bool sphere_roots(V3 oc, V3 d, double a, double r, double tmin, double tmax, double& t_out) {
     const double half_b = dot(oc, d);
     const double c = squared_length(oc) - r * r;
     const double discriminant = half_b * half_b - a * c;
     if (discriminant > 0.0) {
+        if (RT_SCREEN_SPHERE && discriminant > 1e-30 && discriminant < 1e30) {
+            // screen: temp = n / a lies in (tmin, tmax) only if n lies in (tmin*a, tmax*a); f32 sqrt is within 2^-22
+            const double rs = (double)sqrtf((float)discriminant);
+            const double n1 = -half_b - rs, n2 = -half_b + rs;
+            const double lo = tmin * a, hi = tmax * a;
+            const double m = rs * 0x1.0p-20 + (fabs(half_b) + rs) * SCREEN_T + SCREEN_ABS;
+            const double mlo = m + fabs(lo) * SCREEN_T, mhi = m + fabs(hi) * SCREEN_T;
+            const bool out1 = n1 - mhi > hi || n1 + mlo < lo;
+            const bool out2 = n2 - mhi > hi || n2 + mlo < lo;
+            if (out1 && out2) return false;
+        }
         const double root = sqrt(discriminant);
         double temp = (-half_b - root) / a;
         if (temp < tmax && temp > tmin) { t_out = temp; return true; }
@@ -150,16 +187,30 @@ RT_D bool sphere_roots(V3 oc, V3 d, double a, double r, double tmin, double tmax
     return false;
 }
 
-// MovingSphere::center src/hittable.rs:208-211.
+// MovingSphere::center src/hittable.rs:208-211. x / 1.0 == x exactly, so the common shutter (0, 1) needs no division.
 RT_D V3 msphere_center(const RtMovingSphere* s, double time) {
     const V3 c0 = v3p(s->c0), c1 = v3p(s->c1);
-    return c0 + (c1 - c0) * ((time - s->t0) / (s->t1 - s->t0));
+    const double den = s->t1 - s->t0;
+    const double num = time - s->t0;
+    const double f = den == 1.0 ? num : num / den;
+    return c0 + (c1 - c0) * f;
 }
 
 // XYRect/XZRect/YZRect::hit src/aarect.rs:30-39, 81-90, 132-141: plane, then inclusive bounds.
-// (ok, dk) = ray origin/direction along the plane normal, (oa, da), (ob, db) in the plane.
-RT_D bool rect_t(double k, double a0, double a1, double b0, double b1, double ok, double dk, double oa, double da, double ob,
-                 double db, double tmin, double tmax, double& t_out) {
+// (ok, dk) = ray origin/direction along the plane normal, (oa, da), (ob, db) in the plane; ik = 1/dk as rounded
+// by Seg (used by the screen only).
+RT_D bool rect_t(double k, double a0, double a1, double b0, double b1, double ok, double dk, double ik, double oa, double da,
+                 double ob, double db, double tmin, double tmax, double& t_out) {
+    if (RT_SCREEN_RECT) {
+        const double ta = (k - ok) * ik;
+        const double et = fabs(ta) * SCREEN_T + SCREEN_ABS;
+        if (ta + et < tmin || ta - et > tmax) return false;
+        const double pa = ta * da, pb = ta * db;
+        const double aa = oa + pa, ab = ob + pb;
+        const double ea = (fabs(oa) + fabs(pa)) * SCREEN_P + SCREEN_ABS;
+        const double eb = (fabs(ob) + fabs(pb)) * SCREEN_P + SCREEN_ABS;
+        if (aa + ea < a0 || aa - ea > a1 || ab + eb < b0 || ab - eb > b1) return false;
+    }
     const double t = (k - ok) / dk;
     if (t < tmin || t > tmax) return false;
     const double a = oa + t * da;
@@ -169,27 +220,29 @@ RT_D bool rect_t(double k, double a0, double a1, double b0, double b1, double ok
     return true;
 }
 
-RT_D bool rect_hit(const RtRect* r, V3 o, V3 d, double tmin, double tmax, double& t_out) {
+RT_D bool rect_hit(const RtRect* r, const Seg& g, double tmin, double tmax, double& t_out) {
     const uint32_t axis = r->axis;
-    double ok, dk, oa, da, ob, db;
-    if (axis == 0u) { ok = o.z; dk = d.z; oa = o.x; da = d.x; ob = o.y; db = d.y; }
-    else if (axis == 1u) { ok = o.y; dk = d.y; oa = o.x; da = d.x; ob = o.z; db = d.z; }
-    else { ok = o.x; dk = d.x; oa = o.y; da = d.y; ob = o.z; db = d.z; }
-    return rect_t(r->k, r->a0, r->a1, r->b0, r->b1, ok, dk, oa, da, ob, db, tmin, tmax, t_out);
+    const V3 o = g.o, d = g.d;
+    double ok, dk, ik, oa, da, ob, db;
+    if (axis == 0u) { ok = o.z; dk = d.z; ik = g.invd.z; oa = o.x; da = d.x; ob = o.y; db = d.y; }
+    else if (axis == 1u) { ok = o.y; dk = d.y; ik = g.invd.y; oa = o.x; da = d.x; ob = o.z; db = d.z; }
+    else { ok = o.x; dk = d.x; ik = g.invd.x; oa = o.y; da = d.y; ob = o.z; db = d.z; }
+    return rect_t(r->k, r->a0, r->a1, r->b0, r->b1, ok, dk, ik, oa, da, ob, db, tmin, tmax, t_out);
 }
 
 // Box6::hit -> HittableList::hit over the six sides in src/box6.rs:22-71 order, each against the
 // running closest t (src/hittable.rs:151-164). Returns the side index of the last accepted side.
-RT_D bool box6_hit(const RtBox6* b, V3 o, V3 d, double tmin, double& tmax, uint32_t& side_out) {
+RT_D bool box6_hit(const RtBox6* b, const Seg& g, double tmin, double& tmax, uint32_t& side_out) {
     const V3 p0 = v3p(b->p0), p1 = v3p(b->p1);
+    const V3 o = g.o, d = g.d, iv = g.invd;
     bool any = false;
     double t;
-    if (rect_t(p1.z, p0.x, p1.x, p0.y, p1.y, o.z, d.z, o.x, d.x, o.y, d.y, tmin, tmax, t)) { tmax = t; side_out = 0u; any = true; }
-    if (rect_t(p0.z, p0.x, p1.x, p0.y, p1.y, o.z, d.z, o.x, d.x, o.y, d.y, tmin, tmax, t)) { tmax = t; side_out = 1u; any = true; }
-    if (rect_t(p1.y, p0.x, p1.x, p0.z, p1.z, o.y, d.y, o.x, d.x, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 2u; any = true; }
-    if (rect_t(p0.y, p0.x, p1.x, p0.z, p1.z, o.y, d.y, o.x, d.x, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 3u; any = true; }
-    if (rect_t(p1.x, p0.y, p1.y, p0.z, p1.z, o.x, d.x, o.y, d.y, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 4u; any = true; }
-    if (rect_t(p0.x, p0.y, p1.y, p0.z, p1.z, o.x, d.x, o.y, d.y, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 5u; any = true; }
+    if (rect_t(p1.z, p0.x, p1.x, p0.y, p1.y, o.z, d.z, iv.z, o.x, d.x, o.y, d.y, tmin, tmax, t)) { tmax = t; side_out = 0u; any = true; }
+    if (rect_t(p0.z, p0.x, p1.x, p0.y, p1.y, o.z, d.z, iv.z, o.x, d.x, o.y, d.y, tmin, tmax, t)) { tmax = t; side_out = 1u; any = true; }
+    if (rect_t(p1.y, p0.x, p1.x, p0.z, p1.z, o.y, d.y, iv.y, o.x, d.x, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 2u; any = true; }
+    if (rect_t(p0.y, p0.x, p1.x, p0.z, p1.z, o.y, d.y, iv.y, o.x, d.x, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 3u; any = true; }
+    if (rect_t(p1.x, p0.y, p1.y, p0.z, p1.z, o.x, d.x, iv.x, o.y, d.y, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 4u; any = true; }
+    if (rect_t(p0.x, p0.y, p1.y, p0.z, p1.z, o.x, d.x, iv.x, o.y, d.y, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 5u; any = true; }
     return any;
 }
 
@@ -326,27 +379,25 @@ struct Walker {
         const uint32_t kind = meta & 15u;
         const uint32_t idx = meta >> 4;
         switch (kind) {
-            case RT_N_SPHERE: {
-                const RtSphere* s = S.spheres + idx;
+            case RT_N_SPHERE:
+            case RT_N_MSPHERE: {  // one code path: a moving sphere is a sphere about center(r.tm) (src/hittable.rs:216)
+                V3 c;
+                double r;
+                if (kind == RT_N_SPHERE) { const RtSphere* s = S.spheres + idx; c = v3p(s->c); r = s->r; }
+                else { const RtMovingSphere* s = S.msphere + idx; c = msphere_center(s, tm); r = s->r; }
                 double t;
-                if (sphere_roots(g.o - v3p(s->c), g.d, g.dd, s->r, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
-                break;
-            }
-            case RT_N_MSPHERE: {
-                const RtMovingSphere* s = S.msphere + idx;
-                double t;
-                if (sphere_roots(g.o - msphere_center(s, tm), g.d, g.dd, s->r, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
+                if (sphere_roots(g.o - c, g.d, g.dd, r, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
                 break;
             }
             case RT_N_RECT: {
                 double t;
-                if (rect_hit(S.rects + idx, g.o, g.d, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
+                if (rect_hit(S.rects + idx, g, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
                 break;
             }
             case RT_N_BOX6: {
                 uint32_t side = 0u;
                 double t = best.t;
-                if (box6_hit(S.boxes + idx, g.o, g.d, tmin, t, side)) { best.t = t; best.ref = meta; best.aux = side | (cur_xf << 8); }
+                if (box6_hit(S.boxes + idx, g, tmin, t, side)) { best.t = t; best.ref = meta; best.aux = side | (cur_xf << 8); }
                 break;
             }
             case RT_N_TRIANGLE: {
@@ -355,19 +406,23 @@ struct Walker {
                 break;
             }
             case RT_N_XF_ENTER: {
+                const RtXform* x = S.xforms + idx;
                 V3 o = g.o, d = g.d;
-                xf_apply(S.xforms + idx, o, d);
-                g.set(o, d);
+                xf_apply(x, o, d);
+                if (x->kind == 0u) g.set_origin(o);
+                else g.set_xz(o.x, o.z, d.x, d.z);
                 cur_xf = idx + 1u;
                 break;
             }
             case RT_N_XF_EXIT: {
+                // back in the parent's space: its ray is the stored world ray pushed through the parent's chain
                 const RtXform* x = S.xforms + idx;
                 const uint32_t depth = x->depth;
                 cur_xf = depth > 1u ? x->anc[depth - 2u] + 1u : 0u;
                 V3 o, d;
                 ray_at(S, rs, cur_xf, o, d);
-                g.set(o, d);
+                if (x->kind == 0u) g.set_origin(o);   // leaving a Translate: the direction was never changed
+                else g.set_xz(o.x, o.z, d.x, d.z);    // leaving a RotateY: y components were never changed
                 break;
             }
             default: {  // RT_N_MEDIUM, ConstantMedium::hit src/constant_medium.rs:34-89 (mode is 0 here)

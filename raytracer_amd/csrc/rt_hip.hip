@@ -31,9 +31,8 @@ constexpr int kWorkWords = 10;                      // entries + 9 kinds
 
 struct Workspace {
     uint64_t cap_slots = 0;
-    char* base = nullptr;  // one allocation: 14 f64 columns, hit_ref, hit_aux, two queues
+    char* base = nullptr;  // one allocation: two record arrays, hit slots, three radiance columns
     PathState P{};
-    uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* counts = nullptr;              // [0], [1] queue lengths, [2] ray cursor of the extend launch, [3] cursor of rt_trace_*
     unsigned long long* ray_total = nullptr; // [1] + work counters [kWorkWords]
     std::vector<hipEvent_t> events;
@@ -177,17 +176,15 @@ int ensure_workspace(RtScene* s, uint64_t n_slots) {
     }
     if (w.cap_slots >= n_slots) return RT_OK;
     if (w.base) { HIP_TRY(hipFree(w.base)); w.base = nullptr; w.cap_slots = 0; }
-    const uint64_t bytes = n_slots * (14 * sizeof(double) + 4 * sizeof(uint32_t));
+    const uint64_t bytes = n_slots * (2 * sizeof(rtd::RayRec) + sizeof(rtd::HitSlot) + 3 * sizeof(double));
     HIP_TRY(hipMalloc((void**)&w.base, bytes));
-    double* dcol = reinterpret_cast<double*>(w.base);
-    double** cols[14] = {&w.P.ox, &w.P.oy, &w.P.oz, &w.P.dx, &w.P.dy, &w.P.dz, &w.P.tm, &w.P.tr, &w.P.tg, &w.P.tb,
-                         &w.P.lr, &w.P.lg, &w.P.lb, &w.P.hit_t};
-    for (int i = 0; i < 14; ++i) *cols[i] = dcol + (uint64_t)i * n_slots;
-    uint32_t* ucol = reinterpret_cast<uint32_t*>(dcol + 14 * n_slots);
-    w.P.hit_ref = ucol;
-    w.P.hit_aux = ucol + n_slots;
-    w.queue[0] = ucol + 2 * n_slots;
-    w.queue[1] = ucol + 3 * n_slots;
+    char* p = w.base;
+    w.P.rec[0] = reinterpret_cast<rtd::RayRec*>(p); p += n_slots * sizeof(rtd::RayRec);
+    w.P.rec[1] = reinterpret_cast<rtd::RayRec*>(p); p += n_slots * sizeof(rtd::RayRec);
+    w.P.hit = reinterpret_cast<rtd::HitSlot*>(p); p += n_slots * sizeof(rtd::HitSlot);
+    w.P.lr = reinterpret_cast<double*>(p); p += n_slots * sizeof(double);
+    w.P.lg = reinterpret_cast<double*>(p); p += n_slots * sizeof(double);
+    w.P.lb = reinterpret_cast<double*>(p);
     w.cap_slots = n_slots;
     return RT_OK;
 }
@@ -241,18 +238,16 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         const uint32_t grid = grid_for(s, C.n_slots);
         hipLaunchKernelGGL(rtd::k_generate, dim3(grid), dim3(rtd::BLOCK), 0, stream, C, w.P);
         for (uint32_t bounce = 0; bounce < p->max_depth; ++bounce) {
-            const int cur = (int)(bounce & 1u), nxt = cur ^ 1;
-            const uint32_t* q = bounce == 0 ? nullptr : w.queue[cur];
+            const uint32_t cur = bounce & 1u;
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
             if (work)
-                hipLaunchKernelGGL(rtd::k_extend<true>, dim3(s->grid_extend), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts, (uint32_t)cur,
-                                   bounce, w.ray_total + 1);
+                hipLaunchKernelGGL(rtd::k_extend<true>, dim3(s->grid_extend), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, w.counts, cur, bounce,
+                                   w.ray_total + 1);
             else
-                hipLaunchKernelGGL(rtd::k_extend<false>, dim3(s->grid_extend), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts, (uint32_t)cur,
-                                   bounce, (unsigned long long*)nullptr);
+                hipLaunchKernelGGL(rtd::k_extend<false>, dim3(s->grid_extend), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, w.counts, cur, bounce,
+                                   (unsigned long long*)nullptr);
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
-            hipLaunchKernelGGL(rtd::k_shade, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, q, w.counts, (uint32_t)cur, w.queue[nxt],
-                               bounce, w.ray_total);
+            hipLaunchKernelGGL(rtd::k_shade, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, w.counts, cur, bounce, w.ray_total);
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
         }
         hipLaunchKernelGGL(rtd::k_accumulate, dim3(grid_for(s, npix)), dim3(rtd::BLOCK), 0, stream, C, w.P, accum_dev);
