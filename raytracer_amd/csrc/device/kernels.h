@@ -71,6 +71,43 @@ struct RenderConst {
 };
 
 constexpr int BLOCK = 256;
+constexpr int EXT_BLOCK = 768;    // extend: one 12-wave workgroup per CU sharing one LDS copy of the scene tables
+constexpr int TRACE_BLOCK = 512;  // rt_trace_*: also rebuilds the hit record, needs more registers per lane
+
+// Which scene tables the closest-hit kernels copy into LDS at launch (bytes, 0 = read from global memory).
+// The small reference scenes fit entirely (final scene: 37 KB of entries + 27 KB of primitives), so every
+// entry and primitive fetch of the walk is an LDS read instead of a trip through the vector cache.
+struct LdsPlan {
+    uint32_t nodes, spheres, msphere, rects, boxes, triangles, xforms, media;
+};
+
+extern __shared__ uint4 rt_lds[];
+
+RT_D const void* stage_table(const void* src, uint32_t bytes, uint32_t& off) {
+    if (bytes == 0u) return src;
+    const uint32_t chunks = (bytes + 15u) >> 4;  // tables are allocated with 16 bytes of slack
+    uint4* dst = rt_lds + (off >> 4);
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    for (uint32_t k = threadIdx.x; k < chunks; k += blockDim.x) dst[k] = s4[k];
+    off += chunks << 4;
+    return dst;
+}
+
+// Returns the scene with the staged tables redirected to their LDS copies (generic pointers).
+RT_D DevScene stage_scene(const DevScene& S, const LdsPlan& plan) {
+    DevScene L = S;
+    uint32_t off = 0u;
+    L.nodes = static_cast<const RtNode*>(stage_table(S.nodes, plan.nodes, off));
+    L.boxes = static_cast<const RtBox6*>(stage_table(S.boxes, plan.boxes, off));
+    L.spheres = static_cast<const RtSphere*>(stage_table(S.spheres, plan.spheres, off));
+    L.msphere = static_cast<const RtMovingSphere*>(stage_table(S.msphere, plan.msphere, off));
+    L.rects = static_cast<const RtRect*>(stage_table(S.rects, plan.rects, off));
+    L.triangles = static_cast<const RtTriangle*>(stage_table(S.triangles, plan.triangles, off));
+    L.xforms = static_cast<const RtXform*>(stage_table(S.xforms, plan.xforms, off));
+    L.media = static_cast<const RtMedium*>(stage_table(S.media, plan.media, off));
+    __syncthreads();
+    return L;
+}
 
 // minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument)
 #ifndef RT_EXTEND_WAVES
@@ -101,7 +138,7 @@ RT_D void extend_pool(const DevScene& S, IO& io, uint32_t* __restrict__ cursor, 
     if (COUNT) { work.entries = 0; for (int k = 0; k < 9; ++k) work.prim[k] = 0; }
     const uint32_t n = io.n();
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total_waves = gridDim.x * (BLOCK / 64);
+    const uint32_t total_waves = gridDim.x * (blockDim.x / 64u);
     // with few rays, spread them over the waves of the grid instead of filling a few waves completely
     uint32_t max_active = (n + total_waves - 1u) / total_waves;
     max_active = max_active < 8u ? 8u : (max_active > 64u ? 64u : max_active);
@@ -209,9 +246,10 @@ struct TraceIO {
 };
 
 template <bool RECORDS, bool COUNT>
-__global__ void __launch_bounds__(BLOCK) k_trace(DevScene S, const RtRay* __restrict__ rays, uint64_t n, uint64_t seed,
-                                                 RtHit* __restrict__ hits, RtHitRecord* __restrict__ recs,
-                                                 uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
+__global__ void __launch_bounds__(TRACE_BLOCK, 2) k_trace(DevScene S0, LdsPlan plan, const RtRay* __restrict__ rays, uint64_t n, uint64_t seed,
+                                                        RtHit* __restrict__ hits, RtHitRecord* __restrict__ recs,
+                                                        uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
+    const DevScene S = stage_scene(S0, plan);
     TraceIO<RECORDS> io;
     io.rays = rays; io.n_rays = n; io.seed = seed; io.hits = hits; io.recs = recs;
     extend_pool<COUNT>(S, io, cursor, work_out);
@@ -270,9 +308,10 @@ struct ExtendIO {
 // counts[0], counts[1]: lengths of the two record arrays; counts[2]: the ray cursor of this launch (zero on
 // entry, reset by the shade launch that follows).
 template <bool COUNT>
-__global__ void __launch_bounds__(BLOCK, RT_EXTEND_WAVES) k_extend(DevScene S, RenderConst C, PathState P, uint32_t* __restrict__ counts,
-                                                                   uint32_t cur, uint32_t bounce,
-                                                                   unsigned long long* __restrict__ work_out) {
+__global__ void __launch_bounds__(EXT_BLOCK, RT_EXTEND_WAVES) k_extend(DevScene S0, LdsPlan plan, RenderConst C, PathState P,
+                                                                       uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
+                                                                       unsigned long long* __restrict__ work_out) {
+    const DevScene S = stage_scene(S0, plan);
     ExtendIO io;
     io.recs = P.rec[cur]; io.hits = P.hit; io.seed = C.seed; io.npix = C.npix; io.sample0 = C.sample0; io.bounce = bounce;
     io.count = bounce == 0u ? C.n_slots : counts[cur];

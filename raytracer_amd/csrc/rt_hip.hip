@@ -47,6 +47,8 @@ struct RtScene {
     Workspace ws;
     uint32_t n_cus = 256;
     uint32_t grid_extend = 256;  // resident blocks of the persistent closest-hit kernels
+    rtd::LdsPlan plan{};         // tables the closest-hit kernels stage in LDS
+    uint32_t lds_bytes = 0;
 };
 
 namespace {
@@ -136,7 +138,7 @@ int upload(RtScene* s, const T* src, uint64_t n, const T** dst) {
     *dst = nullptr;
     if (n == 0) return RT_OK;
     void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+    HIP_TRY(hipMalloc(&p, n * sizeof(T) + 16));  // 16 bytes of slack: the LDS staging copy reads whole 16-byte chunks
     s->allocs.push_back(p);
     HIP_TRY(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
     *dst = static_cast<const T*>(p);
@@ -156,7 +158,7 @@ uint32_t grid_for(const RtScene* s, uint64_t n) {
 
 // The trace kernels are persistent: never more blocks than can be resident, fewer when there are few rays.
 uint32_t trace_grid(const RtScene* s, uint64_t n) {
-    const uint64_t want = (n + 8 * (rtd::BLOCK / 64) - 1) / (8 * (rtd::BLOCK / 64));
+    const uint64_t want = (n + 8 * (rtd::TRACE_BLOCK / 64) - 1) / (8 * (rtd::TRACE_BLOCK / 64));
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, s->grid_extend));
 }
 
@@ -241,10 +243,10 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
             const uint32_t cur = bounce & 1u;
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
             if (work)
-                hipLaunchKernelGGL(rtd::k_extend<true>, dim3(s->grid_extend), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, w.counts, cur, bounce,
+                hipLaunchKernelGGL(rtd::k_extend<true>, dim3(s->grid_extend), dim3(rtd::EXT_BLOCK), s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce,
                                    w.ray_total + 1);
             else
-                hipLaunchKernelGGL(rtd::k_extend<false>, dim3(s->grid_extend), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, w.counts, cur, bounce,
+                hipLaunchKernelGGL(rtd::k_extend<false>, dim3(s->grid_extend), dim3(rtd::EXT_BLOCK), s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce,
                                    (unsigned long long*)nullptr);
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
             hipLaunchKernelGGL(rtd::k_shade, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, w.counts, cur, bounce, w.ray_total);
@@ -303,8 +305,27 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) { rc = rt::set_error(RT_E_DEVICE, "hipGetDeviceProperties failed"); break; }
         s->n_cus = (uint32_t)std::max(1, prop.multiProcessorCount);
+        // LDS plan: stage tables in priority order while they fit in the 64 KiB a workgroup may ask for dynamically
+        {
+            uint32_t budget = 65536u;
+            auto take = [&](uint64_t bytes) -> uint32_t {
+                const uint64_t padded = (bytes + 15u) & ~15ull;
+                if (bytes == 0 || padded > budget) return 0u;
+                budget -= (uint32_t)padded;
+                return (uint32_t)bytes;
+            };
+            s->plan.nodes = take(d->n_nodes * sizeof(RtNode));
+            s->plan.boxes = take(d->n_boxes * sizeof(RtBox6));
+            s->plan.spheres = take(d->n_spheres * sizeof(RtSphere));
+            s->plan.msphere = take(d->n_msphere * sizeof(RtMovingSphere));
+            s->plan.rects = take(d->n_rects * sizeof(RtRect));
+            s->plan.triangles = take(d->n_triangles * sizeof(RtTriangle));
+            s->plan.xforms = take(d->n_xforms * sizeof(RtXform));
+            s->plan.media = take(d->n_media * sizeof(RtMedium));
+            s->lds_bytes = 65536u - budget;
+        }
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false>, rtd::BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false>, rtd::EXT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
         s->grid_extend = s->n_cus * (uint32_t)per_cu;
         if ((rc = upload(s, d->nodes, d->n_nodes, &s->S.nodes))) break;
         if ((rc = upload(s, d->spheres, d->n_spheres, &s->S.spheres))) break;
@@ -341,7 +362,7 @@ int rt_trace_closest_device(RtScene* s, const RtRay* rays_dev, uint64_t n, uint6
     if (n >= (1ull << 32)) return rt::set_error(RT_E_INVALID, "too many rays in one call");
     if (int rc = ensure_workspace(s, 0)) return rc;
     HIP_TRY(hipMemsetAsync(s->ws.counts + 3, 0, sizeof(uint32_t), (hipStream_t)stream));
-    hipLaunchKernelGGL((rtd::k_trace<false, false>), dim3(trace_grid(s, n)), dim3(rtd::BLOCK), 0, (hipStream_t)stream, s->S, rays_dev, n,
+    hipLaunchKernelGGL((rtd::k_trace<false, false>), dim3(trace_grid(s, n)), dim3(rtd::TRACE_BLOCK), s->lds_bytes, (hipStream_t)stream, s->S, s->plan, rays_dev, n,
                        seed, out_dev, (RtHitRecord*)nullptr, s->ws.counts + 3, (unsigned long long*)nullptr);
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -386,14 +407,14 @@ int trace_host(RtScene* s, const RtRay* rays, uint64_t n, uint64_t seed, RtHit* 
         if (int rc2 = ensure_workspace(s, 0)) return rc2;
         uint32_t* cursor = s->ws.counts + 3;
         HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t), nullptr));
-        const dim3 grid(trace_grid(s, n)), block(rtd::BLOCK);
+        const dim3 grid(trace_grid(s, n)), block(rtd::TRACE_BLOCK);
         HIP_TRY(hipEventRecord(e0, nullptr));
         if (recs) {
-            if (work) hipLaunchKernelGGL((rtd::k_trace<true, true>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)nullptr, (RtHitRecord*)d_out, cursor, d_work);
-            else hipLaunchKernelGGL((rtd::k_trace<true, false>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)nullptr, (RtHitRecord*)d_out, cursor, d_work);
+            if (work) hipLaunchKernelGGL((rtd::k_trace<true, true>), grid, block, s->lds_bytes, nullptr, s->S, s->plan, d_rays, n, seed, (RtHit*)nullptr, (RtHitRecord*)d_out, cursor, d_work);
+            else hipLaunchKernelGGL((rtd::k_trace<true, false>), grid, block, s->lds_bytes, nullptr, s->S, s->plan, d_rays, n, seed, (RtHit*)nullptr, (RtHitRecord*)d_out, cursor, d_work);
         } else {
-            if (work) hipLaunchKernelGGL((rtd::k_trace<false, true>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)d_out, (RtHitRecord*)nullptr, cursor, d_work);
-            else hipLaunchKernelGGL((rtd::k_trace<false, false>), grid, block, 0, nullptr, s->S, d_rays, n, seed, (RtHit*)d_out, (RtHitRecord*)nullptr, cursor, d_work);
+            if (work) hipLaunchKernelGGL((rtd::k_trace<false, true>), grid, block, s->lds_bytes, nullptr, s->S, s->plan, d_rays, n, seed, (RtHit*)d_out, (RtHitRecord*)nullptr, cursor, d_work);
+            else hipLaunchKernelGGL((rtd::k_trace<false, false>), grid, block, s->lds_bytes, nullptr, s->S, s->plan, d_rays, n, seed, (RtHit*)d_out, (RtHitRecord*)nullptr, cursor, d_work);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e1, nullptr));
