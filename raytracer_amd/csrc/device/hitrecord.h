@@ -34,7 +34,8 @@ RT_D void get_sphere_uv(V3 p, double& u, double& v) {
 }
 
 // Ray of the candidate's own space: the world ray pushed through `depth` wrappers, outermost first.
-RT_D void ray_to_depth(const DevScene& S, const RtXform* inner, uint32_t depth, V3& o, V3& d) {
+template <class SC, class PX>
+RT_D void ray_to_depth(const SC& S, PX inner, uint32_t depth, V3& o, V3& d) {
     for (uint32_t k = 0; k < depth; ++k) xf_apply(S.xforms + inner->anc[k], o, d);
 }
 
@@ -55,21 +56,22 @@ RT_D void fill_rect_record(HitRec& rec, V3 o, V3 d, double t, uint32_t axis, dou
 
 // ow, dw, tm: the ray handed to world.hit. `best` must be a hit.
 // want_uv = false skips the spherical u, v (atan2, asin), which only an image texture reads (src/texture.rs:93-98).
-RT_D void build_hit_record(const DevScene& S, V3 ow, V3 dw, double tm, const Cand& best, HitRec& rec, bool want_uv = true) {
+template <class SC>
+RT_D void build_hit_record(const SC& S, V3 ow, V3 dw, double tm, const Cand& best, HitRec& rec, bool want_uv = true) {
     const uint32_t kind = best.ref & 15u;
     const uint32_t idx = best.ref >> 4;
     const uint32_t xf1 = best.aux >> 8;
-    const RtXform* inner = xf1 ? S.xforms + (xf1 - 1u) : nullptr;
-    const uint32_t depth = inner ? inner->depth : 0u;
+    const auto inner = S.xforms + (xf1 ? xf1 - 1u : 0u);  // only dereferenced when xf1 != 0
+    const uint32_t depth = xf1 ? inner->depth : 0u;
     V3 o = ow, d = dw;
-    if (inner) ray_to_depth(S, inner, depth, o, d);
+    if (xf1) ray_to_depth(S, inner, depth, o, d);
     const double t = best.t;
     rec.t = t;
     rec.u = 0.0;
     rec.v = 0.0;
     switch (kind) {
         case RT_N_SPHERE: {  // src/hittable.rs:84-93
-            const RtSphere* s = S.spheres + idx;
+            const auto s = S.spheres + idx;
             const V3 c = v3p(s->c);
             rec.p = at(o, d, t);
             const V3 outward_normal = (rec.p - c) / s->r;
@@ -79,7 +81,7 @@ RT_D void build_hit_record(const DevScene& S, V3 ow, V3 dw, double tm, const Can
             break;
         }
         case RT_N_MSPHERE: {  // src/hittable.rs:227-231 (u, v not written there; 0 here)
-            const RtMovingSphere* s = S.msphere + idx;
+            const auto s = S.msphere + idx;
             rec.p = at(o, d, t);
             const V3 outward_normal = (rec.p - msphere_center(s, tm)) / s->r;
             set_face_normal(rec, d, outward_normal);
@@ -87,13 +89,13 @@ RT_D void build_hit_record(const DevScene& S, V3 ow, V3 dw, double tm, const Can
             break;
         }
         case RT_N_RECT: {
-            const RtRect* r = S.rects + idx;
+            const auto r = S.rects + idx;
             fill_rect_record(rec, o, d, t, r->axis, r->a0, r->a1, r->b0, r->b1);
             rec.mat = r->mat;
             break;
         }
         case RT_N_BOX6: {  // the side that won, src/box6.rs:22-71
-            const RtBox6* b = S.boxes + idx;
+            const auto b = S.boxes + idx;
             const V3 p0 = v3p(b->p0), p1 = v3p(b->p1);
             const uint32_t side = best.aux & 255u;
             if (side < 2u) fill_rect_record(rec, o, d, t, 0u, p0.x, p1.x, p0.y, p1.y);
@@ -103,7 +105,7 @@ RT_D void build_hit_record(const DevScene& S, V3 ow, V3 dw, double tm, const Can
             break;
         }
         case RT_N_TRIANGLE: {  // src/triangle.rs:30-67; u, v recomputed with the same expressions as the test
-            const RtTriangle* tr = S.triangles + idx;
+            const auto tr = S.triangles + idx;
             const V3 point0 = v3p(tr->p0), edge1 = v3p(tr->e1), edge2 = v3p(tr->e2);
             const V3 pvec = cross(d, edge2);
             const double det = dot(pvec, edge1);
@@ -121,7 +123,7 @@ RT_D void build_hit_record(const DevScene& S, V3 ow, V3 dw, double tm, const Can
             break;
         }
         default: {  // RT_N_MEDIUM, src/constant_medium.rs:75-87
-            const RtMedium* m = S.media + idx;
+            const auto m = S.media + idx;
             rec.p = at(o, d, t);
             rec.normal = v3(1.0, 0.0, 0.0);
             rec.front_face = true;
@@ -131,7 +133,7 @@ RT_D void build_hit_record(const DevScene& S, V3 ow, V3 dw, double tm, const Can
     }
     // out through the wrappers, innermost first
     for (uint32_t lvl = depth; lvl > 0u; --lvl) {
-        const RtXform* x = S.xforms + inner->anc[lvl - 1u];
+        const auto x = S.xforms + inner->anc[lvl - 1u];
         // direction of the ray this wrapper handed to its child (Translate keeps it, RotateY rotates it)
         V3 ol = ow, dl = dw;
         for (uint32_t k = 0; k < lvl; ++k) xf_apply(S.xforms + inner->anc[k], ol, dl);
@@ -152,7 +154,8 @@ RT_D void build_hit_record(const DevScene& S, V3 ow, V3 dw, double tm, const Can
 }
 
 // Material of the winning candidate without building the record.
-RT_D uint32_t hit_material(const DevScene& S, const Cand& best) {
+template <class SC>
+RT_D uint32_t hit_material(const SC& S, const Cand& best) {
     const uint32_t idx = best.ref >> 4;
     switch (best.ref & 15u) {
         case RT_N_SPHERE: return S.spheres[idx].mat;
@@ -165,7 +168,8 @@ RT_D uint32_t hit_material(const DevScene& S, const Cand& best) {
 }
 
 // prim_id / sub as RtHit reports them.
-RT_D void hit_ids(const DevScene& S, const Cand& best, uint32_t& prim_id, uint32_t& sub) {
+template <class SC>
+RT_D void hit_ids(const SC& S, const Cand& best, uint32_t& prim_id, uint32_t& sub) {
     const uint32_t kind = best.ref & 15u;
     const uint32_t idx = best.ref >> 4;
     switch (kind) {

@@ -73,38 +73,46 @@ struct RenderConst {
 constexpr int BLOCK = 256;
 constexpr int EXT_BLOCK = 768;    // extend: one 12-wave workgroup per CU sharing one LDS copy of the scene tables
 constexpr int TRACE_BLOCK = 512;  // rt_trace_*: also rebuilds the hit record, needs more registers per lane
+constexpr int SHADE_BLOCK = 512;  // shade: 8 waves per workgroup share the LDS copy of primitive / material / texture tables
 
 // Which scene tables the closest-hit kernels copy into LDS at launch (bytes, 0 = read from global memory).
 // The small reference scenes fit entirely (final scene: 37 KB of entries + 27 KB of primitives), so every
 // entry and primitive fetch of the walk is an LDS read instead of a trip through the vector cache.
 struct LdsPlan {
-    uint32_t nodes, spheres, msphere, rects, boxes, triangles, xforms, media;
+    uint32_t nodes, spheres, msphere, rects, boxes, triangles, xforms, media, materials, textures, perlins;
 };
 
 extern __shared__ uint4 rt_lds[];
 
-RT_D const void* stage_table(const void* src, uint32_t bytes, uint32_t& off) {
-    if (bytes == 0u) return src;
+template <class T>
+RT_D const RT_LDS T* stage_table(const T* src, uint32_t bytes, uint32_t& off) {
     const uint32_t chunks = (bytes + 15u) >> 4;  // tables are allocated with 16 bytes of slack
     uint4* dst = rt_lds + (off >> 4);
     const uint4* s4 = reinterpret_cast<const uint4*>(src);
     for (uint32_t k = threadIdx.x; k < chunks; k += blockDim.x) dst[k] = s4[k];
     off += chunks << 4;
-    return dst;
+    return (const RT_LDS T*)dst;
 }
 
-// Returns the scene with the staged tables redirected to their LDS copies (generic pointers).
-RT_D DevScene stage_scene(const DevScene& S, const LdsPlan& plan) {
-    DevScene L = S;
+// Copies the planned tables into LDS and returns the scene as the kernels of the LDS variant see it. Tables with
+// 0 bytes in the plan are not used by that kernel and keep a dangling (never dereferenced) LDS pointer.
+RT_D SceneT<true> stage_scene(const DevScene& S, const LdsPlan& plan) {
+    SceneT<true> L;
     uint32_t off = 0u;
-    L.nodes = static_cast<const RtNode*>(stage_table(S.nodes, plan.nodes, off));
-    L.boxes = static_cast<const RtBox6*>(stage_table(S.boxes, plan.boxes, off));
-    L.spheres = static_cast<const RtSphere*>(stage_table(S.spheres, plan.spheres, off));
-    L.msphere = static_cast<const RtMovingSphere*>(stage_table(S.msphere, plan.msphere, off));
-    L.rects = static_cast<const RtRect*>(stage_table(S.rects, plan.rects, off));
-    L.triangles = static_cast<const RtTriangle*>(stage_table(S.triangles, plan.triangles, off));
-    L.xforms = static_cast<const RtXform*>(stage_table(S.xforms, plan.xforms, off));
-    L.media = static_cast<const RtMedium*>(stage_table(S.media, plan.media, off));
+    L.nodes = stage_table(S.nodes, plan.nodes, off);
+    L.boxes = stage_table(S.boxes, plan.boxes, off);
+    L.spheres = stage_table(S.spheres, plan.spheres, off);
+    L.msphere = stage_table(S.msphere, plan.msphere, off);
+    L.rects = stage_table(S.rects, plan.rects, off);
+    L.triangles = stage_table(S.triangles, plan.triangles, off);
+    L.xforms = stage_table(S.xforms, plan.xforms, off);
+    L.media = stage_table(S.media, plan.media, off);
+    L.materials = stage_table(S.materials, plan.materials, off);
+    L.textures = stage_table(S.textures, plan.textures, off);
+    L.perlins = stage_table(S.perlins, plan.perlins, off);
+    L.images = S.images;
+    L.texels = S.texels;
+    L.n_nodes = S.n_nodes;
     __syncthreads();
     return L;
 }
@@ -132,8 +140,8 @@ RT_D DevScene stage_scene(const DevScene& S, const LdsPlan& plan) {
 #endif
 constexpr uint32_t REFILL_LANES = RT_REFILL_LANES;  // refill when at least this many lanes are idle
 
-template <bool COUNT, class IO>
-RT_D void extend_pool(const DevScene& S, IO& io, uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
+template <bool COUNT, class SC, class IO>
+RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
     Work work;
     if (COUNT) { work.entries = 0; for (int k = 0; k < 9; ++k) work.prim[k] = 0; }
     const uint32_t n = io.n();
@@ -214,7 +222,8 @@ struct TraceIO {
         r.key.seed = seed; r.key.pixel = q->pixel; r.key.sample = q->sample; r.key.bounce = q->bounce;
         r.rs.r = q;
     }
-    RT_D void store(const DevScene& S, uint32_t i, const Ray& r, const Cand& best) const {
+    template <class SC>
+    RT_D void store(const SC& S, uint32_t i, const Ray& r, const Cand& best) const {
         V3 o, d;
         r.rs.load(o, d);
         if (RECORDS) {
@@ -245,14 +254,19 @@ struct TraceIO {
     }
 };
 
-template <bool RECORDS, bool COUNT>
+// LDS = true: every table the kernel reads (all but images / texels) is staged in LDS first.
+template <bool RECORDS, bool COUNT, bool LDS>
 __global__ void __launch_bounds__(TRACE_BLOCK, 2) k_trace(DevScene S0, LdsPlan plan, const RtRay* __restrict__ rays, uint64_t n, uint64_t seed,
                                                         RtHit* __restrict__ hits, RtHitRecord* __restrict__ recs,
                                                         uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
-    const DevScene S = stage_scene(S0, plan);
     TraceIO<RECORDS> io;
     io.rays = rays; io.n_rays = n; io.seed = seed; io.hits = hits; io.recs = recs;
-    extend_pool<COUNT>(S, io, cursor, work_out);
+    if constexpr (LDS) {
+        const SceneT<true> S = stage_scene(S0, plan);
+        extend_pool<COUNT>(S, io, cursor, work_out);
+    } else {
+        extend_pool<COUNT>(S0, io, cursor, work_out);
+    }
 }
 
 // ---- generate: camera rays of one batch (src/main.rs:206-209, src/camera.rs:61-71) ---------
@@ -298,7 +312,8 @@ struct ExtendIO {
         load_ray64(recs + i, r.o, r.d, r.tm, slot);
         r.key.seed = seed; r.key.pixel = slot % npix; r.key.sample = sample0 + slot / npix; r.key.bounce = bounce;
     }
-    RT_D void store(const DevScene&, uint32_t i, const Ray&, const Cand& best) const {
+    template <class SC>
+    RT_D void store(const SC&, uint32_t i, const Ray&, const Cand& best) const {
         uint4 h;
         h.x = (uint32_t)__double2loint(best.t); h.y = (uint32_t)__double2hiint(best.t); h.z = best.ref; h.w = best.aux;
         *reinterpret_cast<uint4*>(hits + i) = h;
@@ -307,24 +322,28 @@ struct ExtendIO {
 
 // counts[0], counts[1]: lengths of the two record arrays; counts[2]: the ray cursor of this launch (zero on
 // entry, reset by the shade launch that follows).
-template <bool COUNT>
+template <bool COUNT, bool LDS>
 __global__ void __launch_bounds__(EXT_BLOCK, RT_EXTEND_WAVES) k_extend(DevScene S0, LdsPlan plan, RenderConst C, PathState P,
                                                                        uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
                                                                        unsigned long long* __restrict__ work_out) {
-    const DevScene S = stage_scene(S0, plan);
     ExtendIO io;
     io.recs = P.rec[cur]; io.hits = P.hit; io.seed = C.seed; io.npix = C.npix; io.sample0 = C.sample0; io.bounce = bounce;
     io.count = bounce == 0u ? C.n_slots : counts[cur];
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[cur ^ 1u] = 0u;  // the array the following shade launch appends to
-    extend_pool<COUNT>(S, io, counts + 2, work_out);
+    if constexpr (LDS) {
+        const SceneT<true> S = stage_scene(S0, plan);
+        extend_pool<COUNT>(S, io, counts + 2, work_out);
+    } else {
+        extend_pool<COUNT>(S0, io, counts + 2, work_out);
+    }
 }
 
 // ---- shade ---------------------------------------------------------------------------------
 // The body of ray_color after world.hit (src/color.rs:42-62), unrolled from recursion into
 // L += T * emitted; T *= attenuation. Survivors go to the other record array.
-__global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DevScene S, RenderConst C, PathState P, uint32_t* __restrict__ counts,
-                                                                 uint32_t cur, uint32_t bounce,
-                                                                 unsigned long long* __restrict__ ray_total) {
+template <class SC>
+RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
+                    unsigned long long* __restrict__ ray_total) {
     const uint32_t n = bounce == 0u ? C.n_slots : counts[cur];
     uint32_t* next_count = counts + (cur ^ 1u);
     const RayRec* recs = P.rec[cur];
@@ -333,10 +352,10 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DevScene S, Ren
         atomicAdd(ray_total, (unsigned long long)n);
         counts[2] = 0u;  // ray cursor of the next extend launch
     }
-    const uint32_t stride = gridDim.x * BLOCK;
+    const uint32_t stride = gridDim.x * SHADE_BLOCK;
     // every lane of a wave runs the same number of iterations so that the ballot below sees whole waves
     const uint32_t n_round = (n + 63u) & ~63u;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += stride) {
+    for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_round; i += stride) {
         bool alive = false;
         V3 no = v3(0.0, 0.0, 0.0), nd = no, T = no;
         double tm = 0.0;
@@ -352,7 +371,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DevScene S, Ren
                 const V3 add = elemul(T, v3p(C.bg));  // src/color.rs:41-43
                 P.lr[slot] += add.x; P.lg[slot] += add.y; P.lb[slot] += add.z;
             } else {
-                const RtMaterial* M = S.materials + hit_material(S, best);
+                const auto M = S.materials + hit_material(S, best);
                 const uint32_t mkind = M->kind;
                 const bool textured = material_has_texture(mkind);
                 const bool want_uv = textured && S.textures[M->tex].kind == RT_T_IMAGE;
@@ -385,6 +404,18 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade(DevScene S, Ren
             base = __shfl(base, leader, 64);
             if (alive) store_ray(next + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), no, nd, tm, slot, T);
         }
+    }
+}
+
+template <bool LDS>
+__global__ void __launch_bounds__(SHADE_BLOCK, RT_SHADE_WAVES) k_shade(DevScene S0, LdsPlan plan, RenderConst C, PathState P,
+                                                                       uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
+                                                                       unsigned long long* __restrict__ ray_total) {
+    if constexpr (LDS) {
+        const SceneT<true> S = stage_scene(S0, plan);
+        shade_all(S, C, P, counts, cur, bounce, ray_total);
+    } else {
+        shade_all(S0, C, P, counts, cur, bounce, ray_total);
     }
 }
 

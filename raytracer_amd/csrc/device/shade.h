@@ -43,7 +43,8 @@ RT_D int f64_to_i32_sat(double f) {  // Rust `as i32`: saturating, NaN -> 0
     return (int)f;
 }
 
-RT_D double perlin_noise(const RtPerlin* P, V3 p) {  // noise :66-89 + perlin_interp :44-63
+template <class PP>
+RT_D double perlin_noise(PP P, V3 p) {  // noise :66-89 + perlin_interp :44-63
     const double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
     const double u = p.x - fx, v = p.y - fy, w = p.z - fz;
     const uint32_t i = (uint32_t)f64_to_i32_sat(fx);
@@ -69,7 +70,8 @@ RT_D double perlin_noise(const RtPerlin* P, V3 p) {  // noise :66-89 + perlin_in
     return accum;
 }
 
-RT_D double perlin_turb(const RtPerlin* P, V3 p, int depth) {  // :91-103
+template <class PP>
+RT_D double perlin_turb(PP P, V3 p, int depth) {  // :91-103
     double accum = 0.0;
     V3 temp_p = p;
     double weight = 1.0;
@@ -90,8 +92,9 @@ RT_D uint32_t f64_to_u32_sat(double f) {  // Rust `as u32`
     return (uint32_t)f;
 }
 
-RT_D V3 texture_value(const DevScene& S, uint32_t tex, double u, double v, V3 p) {
-    const RtTexture* T = S.textures + tex;
+template <class SC>
+RT_D V3 texture_value(const SC& S, uint32_t tex, double u, double v, V3 p) {
+    const auto T = S.textures + tex;
     switch (T->kind) {
         case RT_T_SOLID: return v3p(T->a);  // src/texture.rs:22-26
         case RT_T_CHECKER: {                // :42-51
@@ -134,7 +137,8 @@ RT_D bool material_has_texture(uint32_t kind) { return kind == RT_M_LAMBERTIAN |
 // scatter (src/material.rs:35-50, 68-83, 97-141, 167-175, 196-210). `din` = r_in.dire, `texv` = the material's
 // texture value at the hit. Returns false when the path ends here. A zero-length incoming direction (the
 // reference would panic in Vec3::unit, src/vec3.rs:285-286) also ends the path.
-RT_D bool material_scatter(const RtMaterial* M, V3 din, const HitRec& rec, V3 texv, rt::Rng& rng, V3& attenuation, V3& dout) {
+template <class PMAT>
+RT_D bool material_scatter(PMAT M, V3 din, const HitRec& rec, V3 texv, rt::Rng& rng, V3& attenuation, V3& dout) {
     switch (M->kind) {
         case RT_M_LAMBERTIAN: {
             dout = rec.normal + random_unit_vector(rng);

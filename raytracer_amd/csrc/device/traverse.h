@@ -24,22 +24,42 @@ namespace rtd {
 
 constexpr double D_INF = __builtin_huge_val();
 
-struct DevScene {
-    const RtNode* nodes;
-    const RtSphere* spheres;
-    const RtMovingSphere* msphere;
-    const RtRect* rects;
-    const RtBox6* boxes;
-    const RtTriangle* triangles;
-    const RtXform* xforms;
-    const RtMedium* media;
-    const RtMaterial* materials;
-    const RtTexture* textures;
-    const RtPerlin* perlins;
+// Pointers to the scene tables. IN_LDS = true: the staged copies in LDS (address space 3); images and texels
+// always stay in global memory.
+template <bool IN_LDS> struct TablePtr { template <class T> using type = const T*; };
+template <> struct TablePtr<true> { template <class T> using type = const RT_LDS T*; };
+
+template <bool IN_LDS>
+struct SceneT {
+    template <class T> using P = typename TablePtr<IN_LDS>::template type<T>;
+    P<RtNode> nodes;
+    P<RtSphere> spheres;
+    P<RtMovingSphere> msphere;
+    P<RtRect> rects;
+    P<RtBox6> boxes;
+    P<RtTriangle> triangles;
+    P<RtXform> xforms;
+    P<RtMedium> media;
+    P<RtMaterial> materials;
+    P<RtTexture> textures;
+    P<RtPerlin> perlins;
     const RtImage* images;
     const uint8_t* texels;
     uint32_t n_nodes;
 };
+using DevScene = SceneT<false>;
+
+RT_D void load_node(const RtNode* p, uint4& a, uint4& b) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    a = q[0]; b = q[1];
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+RT_D void load_node(const RT_LDS RtNode* p, uint4& a, uint4& b) {
+    const RT_LDS u32x4* q = reinterpret_cast<const RT_LDS u32x4*>(p);
+    const u32x4 x = q[0], y = q[1];
+    a = make_uint4(x.x, x.y, x.z, x.w);
+    b = make_uint4(y.x, y.y, y.z, y.w);
+}
 
 struct RayKey {  // identifies the path for the counter-based RNG
     uint64_t seed;
@@ -73,7 +93,8 @@ struct RayAoS {  // RtRay
 
 // ---- wrappers: ray into object space -------------------------------------------
 // Translate::hit src/hittable.rs:278-282; RotateY::hit :355-368.
-RT_D void xf_apply(const RtXform* x, V3& o, V3& d) {
+template <class PX>
+RT_D void xf_apply(PX x, V3& o, V3& d) {
     if (x->kind == 0u) {
         o = o - v3p(x->offset);
     } else {
@@ -87,11 +108,11 @@ RT_D void xf_apply(const RtXform* x, V3& o, V3& d) {
 }
 
 // The ray as seen inside wrapper xf1 - 1 (xf1 == 0: the world ray).
-template <class RS>
-RT_D void ray_at(const DevScene& S, const RS& rs, uint32_t xf1, V3& o, V3& d) {
+template <class SC, class RS>
+RT_D void ray_at(const SC& S, const RS& rs, uint32_t xf1, V3& o, V3& d) {
     rs.load(o, d);
     if (xf1) {
-        const RtXform* x = S.xforms + (xf1 - 1u);
+        const auto x = S.xforms + (xf1 - 1u);
         const uint32_t depth = x->depth;
         for (uint32_t k = 0; k < depth; ++k) xf_apply(S.xforms + x->anc[k], o, d);
     }
@@ -188,7 +209,8 @@ RT_D bool sphere_roots(V3 oc, V3 d, double a, double r, double tmin, double tmax
 }
 
 // MovingSphere::center src/hittable.rs:208-211. x / 1.0 == x exactly, so the common shutter (0, 1) needs no division.
-RT_D V3 msphere_center(const RtMovingSphere* s, double time) {
+template <class PM>
+RT_D V3 msphere_center(PM s, double time) {
     const V3 c0 = v3p(s->c0), c1 = v3p(s->c1);
     const double den = s->t1 - s->t0;
     const double num = time - s->t0;
@@ -220,7 +242,8 @@ RT_D bool rect_t(double k, double a0, double a1, double b0, double b1, double ok
     return true;
 }
 
-RT_D bool rect_hit(const RtRect* r, const Seg& g, double tmin, double tmax, double& t_out) {
+template <class PR>
+RT_D bool rect_hit(PR r, const Seg& g, double tmin, double tmax, double& t_out) {
     const uint32_t axis = r->axis;
     const V3 o = g.o, d = g.d;
     double ok, dk, ik, oa, da, ob, db;
@@ -232,7 +255,8 @@ RT_D bool rect_hit(const RtRect* r, const Seg& g, double tmin, double tmax, doub
 
 // Box6::hit -> HittableList::hit over the six sides in src/box6.rs:22-71 order, each against the
 // running closest t (src/hittable.rs:151-164). Returns the side index of the last accepted side.
-RT_D bool box6_hit(const RtBox6* b, const Seg& g, double tmin, double& tmax, uint32_t& side_out) {
+template <class PB>
+RT_D bool box6_hit(PB b, const Seg& g, double tmin, double& tmax, uint32_t& side_out) {
     const V3 p0 = v3p(b->p0), p1 = v3p(b->p1);
     const V3 o = g.o, d = g.d, iv = g.invd;
     bool any = false;
@@ -247,7 +271,8 @@ RT_D bool box6_hit(const RtBox6* b, const Seg& g, double tmin, double& tmax, uin
 }
 
 // Triangle::hit src/triangle.rs:26-59 (Moeller-Trumbore, two-sided, t range inclusive).
-RT_D bool triangle_hit(const RtTriangle* tr, V3 o, V3 d, double tmin, double tmax, double& t_out) {
+template <class PT>
+RT_D bool triangle_hit(PT tr, V3 o, V3 d, double tmin, double tmax, double& t_out) {
     const V3 point0 = v3p(tr->p0), edge1 = v3p(tr->e1), edge2 = v3p(tr->e2);
     const V3 pvec = cross(d, edge2);
     const double det = dot(pvec, edge1);
@@ -270,7 +295,8 @@ RT_D bool triangle_hit(const RtTriangle* tr, V3 o, V3 d, double tmin, double tma
 // single Sphere: boundary.hit(r, -inf, inf) and boundary.hit(r, t1 + 0.0001, inf) evaluate the same quadratic,
 // so the roots are computed once and run through Sphere::hit's two range checks twice. `queries` = how many of
 // the two Sphere::hit calls the reference would have made (the second only after the first hit).
-RT_D bool sphere_boundary(const RtSphere* s, const Seg& g, double& t1, double& t2, uint32_t& queries) {
+template <class PS>
+RT_D bool sphere_boundary(PS s, const Seg& g, double& t1, double& t2, uint32_t& queries) {
     queries = 1u;
     const V3 oc = g.o - v3p(s->c);
     const double a = g.dd;
@@ -313,7 +339,8 @@ struct Walker {
     uint4 na, nb;             // the entry box_run() stopped on
     bool done;
 
-    RT_D void init(const DevScene& S, V3 o, V3 d, double tm_, double tmin_, double tmax_) {
+    template <class SC>
+    RT_D void init(const SC& S, V3 o, V3 d, double tm_, double tmin_, double tmax_) {
         g.set(o, d);
         tm = tm_; tmin0 = tmin_; tmin = tmin_;
         best.t = tmax_; best.ref = RT_MISS; best.aux = 0u;
@@ -323,8 +350,9 @@ struct Walker {
     }
 
     // ConstantMedium::hit after its two boundary queries, src/constant_medium.rs:52-88
-    RT_D void resolve_medium(const DevScene& S, const RayKey& key, uint32_t meta, double t1, double t2) {
-        const RtMedium* m = S.media + (meta >> 4);
+    template <class SC>
+    RT_D void resolve_medium(const SC& S, const RayKey& key, uint32_t meta, double t1, double t2) {
+        const auto m = S.media + (meta >> 4);
         if (t1 < tmin) t1 = tmin;
         if (t2 > best.t) t2 = best.t;
         if (t1 > t2) return;
@@ -340,7 +368,8 @@ struct Walker {
         best.aux = cur_xf << 8;
     }
 
-    RT_D void box_run(const DevScene& S, const RayKey& key, Work* work) {
+    template <class SC>
+    RT_D void box_run(const SC& S, const RayKey& key, Work* work) {
         for (;;) {
             if (i >= end) {
                 if (mode == 0u) { done = true; return; }
@@ -364,17 +393,15 @@ struct Walker {
                 if (inside) resolve_medium(S, key, med_meta, t_enter, t2);
                 continue;
             }
-            const uint4* np = reinterpret_cast<const uint4*>(S.nodes + i);
-            na = np[0];
-            nb = np[1];
+            load_node(S.nodes + i, na, nb);
             if (COUNT) { work->entries++; work->prim[nb.z & 15u]++; }
             if ((nb.z & 15u) != RT_N_INNER) return;
             i = box_hit(na, nb, g, tmin, best.t) ? i + 1u : nb.w;
         }
     }
 
-    template <class RS>
-    RT_D void leaf(const DevScene& S, const RS& rs, const RayKey& key, Work* work) {
+    template <class SC, class RS>
+    RT_D void leaf(const SC& S, const RS& rs, const RayKey& key, Work* work) {
         const uint32_t meta = nb.z;
         const uint32_t kind = meta & 15u;
         const uint32_t idx = meta >> 4;
@@ -383,8 +410,8 @@ struct Walker {
             case RT_N_MSPHERE: {  // one code path: a moving sphere is a sphere about center(r.tm) (src/hittable.rs:216)
                 V3 c;
                 double r;
-                if (kind == RT_N_SPHERE) { const RtSphere* s = S.spheres + idx; c = v3p(s->c); r = s->r; }
-                else { const RtMovingSphere* s = S.msphere + idx; c = msphere_center(s, tm); r = s->r; }
+                if (kind == RT_N_SPHERE) { const auto s = S.spheres + idx; c = v3p(s->c); r = s->r; }
+                else { const auto s = S.msphere + idx; c = msphere_center(s, tm); r = s->r; }
                 double t;
                 if (sphere_roots(g.o - c, g.d, g.dd, r, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
                 break;
@@ -406,7 +433,7 @@ struct Walker {
                 break;
             }
             case RT_N_XF_ENTER: {
-                const RtXform* x = S.xforms + idx;
+                const auto x = S.xforms + idx;
                 V3 o = g.o, d = g.d;
                 xf_apply(x, o, d);
                 if (x->kind == 0u) g.set_origin(o);
@@ -416,7 +443,7 @@ struct Walker {
             }
             case RT_N_XF_EXIT: {
                 // back in the parent's space: its ray is the stored world ray pushed through the parent's chain
-                const RtXform* x = S.xforms + idx;
+                const auto x = S.xforms + idx;
                 const uint32_t depth = x->depth;
                 cur_xf = depth > 1u ? x->anc[depth - 2u] + 1u : 0u;
                 V3 o, d;
@@ -454,8 +481,8 @@ struct Walker {
 };
 
 // One query start to finish (the stand-alone trace kernels).
-template <bool COUNT, class RS>
-RT_D void closest_hit(const DevScene& S, const RS& rs, V3 o0, V3 d0, double tm, double tmin0, double tmax0, const RayKey& key,
+template <bool COUNT, class SC, class RS>
+RT_D void closest_hit(const SC& S, const RS& rs, V3 o0, V3 d0, double tm, double tmin0, double tmax0, const RayKey& key,
                       Cand& best, Work* work) {
     Walker<COUNT> w;
     w.init(S, o0, d0, tm, tmin0, tmax0);

@@ -15,6 +15,11 @@ struct V3 {
 
 RT_D V3 v3(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 RT_D V3 v3p(const double* p) { return v3(p[0], p[1], p[2]); }
+
+// Tables staged in LDS are reached through address-space-3 pointers, so that the compiler emits ds_read (which
+// only waits on the LDS counter) instead of flat loads (which wait on the global-memory counter as well).
+#define RT_LDS __attribute__((address_space(3)))
+RT_D V3 v3p(const RT_LDS double* p) { return v3(p[0], p[1], p[2]); }
 RT_D V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }        // src/vec3.rs:88-98
 RT_D V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }        // :132-141
 RT_D V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }                             // :241-250

@@ -49,6 +49,10 @@ struct RtScene {
     uint32_t grid_extend = 256;  // resident blocks of the persistent closest-hit kernels
     rtd::LdsPlan plan{};         // tables the closest-hit kernels stage in LDS
     uint32_t lds_bytes = 0;
+    rtd::LdsPlan plan_shade{};   // tables the shade kernel stages in LDS
+    uint32_t lds_bytes_shade = 0;
+    uint32_t grid_shade = 256;
+    bool extend_lds = false, shade_lds = false;  // which variant of each kernel this scene runs
 };
 
 namespace {
@@ -242,14 +246,23 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         for (uint32_t bounce = 0; bounce < p->max_depth; ++bounce) {
             const uint32_t cur = bounce & 1u;
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
-            if (work)
-                hipLaunchKernelGGL(rtd::k_extend<true>, dim3(s->grid_extend), dim3(rtd::EXT_BLOCK), s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce,
-                                   w.ray_total + 1);
-            else
-                hipLaunchKernelGGL(rtd::k_extend<false>, dim3(s->grid_extend), dim3(rtd::EXT_BLOCK), s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce,
-                                   (unsigned long long*)nullptr);
+            {
+                const dim3 eg(s->grid_extend), eb(rtd::EXT_BLOCK);
+                unsigned long long* wk = work ? w.ray_total + 1 : nullptr;
+                if (s->extend_lds) {
+                    if (work) hipLaunchKernelGGL((rtd::k_extend<true, true>), eg, eb, s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
+                    else hipLaunchKernelGGL((rtd::k_extend<false, true>), eg, eb, s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
+                } else {
+                    if (work) hipLaunchKernelGGL((rtd::k_extend<true, false>), eg, eb, 0, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
+                    else hipLaunchKernelGGL((rtd::k_extend<false, false>), eg, eb, 0, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
+                }
+            }
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
-            hipLaunchKernelGGL(rtd::k_shade, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P, w.counts, cur, bounce, w.ray_total);
+            {
+                const dim3 sg(std::min(s->grid_shade, (C.n_slots + rtd::SHADE_BLOCK - 1) / rtd::SHADE_BLOCK)), sb(rtd::SHADE_BLOCK);
+                if (s->shade_lds) hipLaunchKernelGGL(rtd::k_shade<true>, sg, sb, s->lds_bytes_shade, stream, s->S, s->plan_shade, C, w.P, w.counts, cur, bounce, w.ray_total);
+                else hipLaunchKernelGGL(rtd::k_shade<false>, sg, sb, 0, stream, s->S, s->plan_shade, C, w.P, w.counts, cur, bounce, w.ray_total);
+            }
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
         }
         hipLaunchKernelGGL(rtd::k_accumulate, dim3(grid_for(s, npix)), dim3(rtd::BLOCK), 0, stream, C, w.P, accum_dev);
@@ -305,28 +318,53 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) { rc = rt::set_error(RT_E_DEVICE, "hipGetDeviceProperties failed"); break; }
         s->n_cus = (uint32_t)std::max(1, prop.multiProcessorCount);
-        // LDS plan: stage tables in priority order while they fit in the 64 KiB a workgroup may ask for dynamically
+        // LDS plans: a kernel runs its LDS variant when every table it reads (all but images / texels) fits
         {
-            uint32_t budget = 65536u;
-            auto take = [&](uint64_t bytes) -> uint32_t {
-                const uint64_t padded = (bytes + 15u) & ~15ull;
-                if (bytes == 0 || padded > budget) return 0u;
-                budget -= (uint32_t)padded;
-                return (uint32_t)bytes;
-            };
-            s->plan.nodes = take(d->n_nodes * sizeof(RtNode));
-            s->plan.boxes = take(d->n_boxes * sizeof(RtBox6));
-            s->plan.spheres = take(d->n_spheres * sizeof(RtSphere));
-            s->plan.msphere = take(d->n_msphere * sizeof(RtMovingSphere));
-            s->plan.rects = take(d->n_rects * sizeof(RtRect));
-            s->plan.triangles = take(d->n_triangles * sizeof(RtTriangle));
-            s->plan.xforms = take(d->n_xforms * sizeof(RtXform));
-            s->plan.media = take(d->n_media * sizeof(RtMedium));
-            s->lds_bytes = 65536u - budget;
+            const uint32_t kBudget = 144u * 1024u;  // of the 160 KiB of a CU; one workgroup per CU
+            auto pad = [](uint64_t bytes) { return (bytes + 15u) & ~15ull; };
+            const uint64_t prims = pad(d->n_spheres * sizeof(RtSphere)) + pad(d->n_msphere * sizeof(RtMovingSphere)) + pad(d->n_rects * sizeof(RtRect)) +
+                                   pad(d->n_boxes * sizeof(RtBox6)) + pad(d->n_triangles * sizeof(RtTriangle)) + pad(d->n_xforms * sizeof(RtXform)) +
+                                   pad(d->n_media * sizeof(RtMedium));
+            const uint64_t ext = pad(d->n_nodes * sizeof(RtNode)) + prims;
+            const uint64_t shd = prims + pad(d->n_materials * sizeof(RtMaterial)) + pad(d->n_textures * sizeof(RtTexture)) + pad(d->n_perlins * sizeof(RtPerlin));
+            rtd::LdsPlan all{};
+            all.spheres = (uint32_t)(d->n_spheres * sizeof(RtSphere)); all.msphere = (uint32_t)(d->n_msphere * sizeof(RtMovingSphere));
+            all.rects = (uint32_t)(d->n_rects * sizeof(RtRect)); all.boxes = (uint32_t)(d->n_boxes * sizeof(RtBox6));
+            all.triangles = (uint32_t)(d->n_triangles * sizeof(RtTriangle)); all.xforms = (uint32_t)(d->n_xforms * sizeof(RtXform));
+            all.media = (uint32_t)(d->n_media * sizeof(RtMedium));
+            if (ext <= kBudget) {
+                s->plan = all;
+                s->plan.nodes = (uint32_t)(d->n_nodes * sizeof(RtNode));
+                s->lds_bytes = (uint32_t)ext;
+            }
+            if (shd <= kBudget) {
+                s->plan_shade = all;
+                s->plan_shade.materials = (uint32_t)(d->n_materials * sizeof(RtMaterial));
+                s->plan_shade.textures = (uint32_t)(d->n_textures * sizeof(RtTexture));
+                s->plan_shade.perlins = (uint32_t)(d->n_perlins * sizeof(RtPerlin));
+                s->lds_bytes_shade = (uint32_t)shd;
+            }
+            s->extend_lds = ext <= kBudget && d->n_nodes > 0;
+            s->shade_lds = shd <= kBudget && d->n_nodes > 0;
+            const int big = (int)kBudget;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
         }
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false>, rtd::EXT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+        hipError_t oe = s->extend_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, true>, rtd::EXT_BLOCK, s->lds_bytes)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, false>, rtd::EXT_BLOCK, 0);
+        if (oe != hipSuccess || per_cu < 1) per_cu = 1;
         s->grid_extend = s->n_cus * (uint32_t)per_cu;
+        int shade_per_cu = 0;
+        oe = s->shade_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, rtd::k_shade<true>, rtd::SHADE_BLOCK, s->lds_bytes_shade)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, rtd::k_shade<false>, rtd::SHADE_BLOCK, 0);
+        if (oe != hipSuccess || shade_per_cu < 1) shade_per_cu = 1;
+        s->grid_shade = s->n_cus * (uint32_t)shade_per_cu * 4u;
         if ((rc = upload(s, d->nodes, d->n_nodes, &s->S.nodes))) break;
         if ((rc = upload(s, d->spheres, d->n_spheres, &s->S.spheres))) break;
         if ((rc = upload(s, d->msphere, d->n_msphere, &s->S.msphere))) break;
@@ -362,8 +400,12 @@ int rt_trace_closest_device(RtScene* s, const RtRay* rays_dev, uint64_t n, uint6
     if (n >= (1ull << 32)) return rt::set_error(RT_E_INVALID, "too many rays in one call");
     if (int rc = ensure_workspace(s, 0)) return rc;
     HIP_TRY(hipMemsetAsync(s->ws.counts + 3, 0, sizeof(uint32_t), (hipStream_t)stream));
-    hipLaunchKernelGGL((rtd::k_trace<false, false>), dim3(trace_grid(s, n)), dim3(rtd::TRACE_BLOCK), s->lds_bytes, (hipStream_t)stream, s->S, s->plan, rays_dev, n,
-                       seed, out_dev, (RtHitRecord*)nullptr, s->ws.counts + 3, (unsigned long long*)nullptr);
+    if (s->extend_lds)
+        hipLaunchKernelGGL((rtd::k_trace<false, false, true>), dim3(trace_grid(s, n)), dim3(rtd::TRACE_BLOCK), s->lds_bytes, (hipStream_t)stream, s->S, s->plan,
+                           rays_dev, n, seed, out_dev, (RtHitRecord*)nullptr, s->ws.counts + 3, (unsigned long long*)nullptr);
+    else
+        hipLaunchKernelGGL((rtd::k_trace<false, false, false>), dim3(trace_grid(s, n)), dim3(rtd::TRACE_BLOCK), 0, (hipStream_t)stream, s->S, s->plan,
+                           rays_dev, n, seed, out_dev, (RtHitRecord*)nullptr, s->ws.counts + 3, (unsigned long long*)nullptr);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -409,13 +451,21 @@ int trace_host(RtScene* s, const RtRay* rays, uint64_t n, uint64_t seed, RtHit* 
         HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t), nullptr));
         const dim3 grid(trace_grid(s, n)), block(rtd::TRACE_BLOCK);
         HIP_TRY(hipEventRecord(e0, nullptr));
-        if (recs) {
-            if (work) hipLaunchKernelGGL((rtd::k_trace<true, true>), grid, block, s->lds_bytes, nullptr, s->S, s->plan, d_rays, n, seed, (RtHit*)nullptr, (RtHitRecord*)d_out, cursor, d_work);
-            else hipLaunchKernelGGL((rtd::k_trace<true, false>), grid, block, s->lds_bytes, nullptr, s->S, s->plan, d_rays, n, seed, (RtHit*)nullptr, (RtHitRecord*)d_out, cursor, d_work);
-        } else {
-            if (work) hipLaunchKernelGGL((rtd::k_trace<false, true>), grid, block, s->lds_bytes, nullptr, s->S, s->plan, d_rays, n, seed, (RtHit*)d_out, (RtHitRecord*)nullptr, cursor, d_work);
-            else hipLaunchKernelGGL((rtd::k_trace<false, false>), grid, block, s->lds_bytes, nullptr, s->S, s->plan, d_rays, n, seed, (RtHit*)d_out, (RtHitRecord*)nullptr, cursor, d_work);
+        RtHit* oh = recs ? nullptr : (RtHit*)d_out;
+        RtHitRecord* orc = recs ? (RtHitRecord*)d_out : nullptr;
+#define RT_LAUNCH_TRACE(R, W, L) hipLaunchKernelGGL((rtd::k_trace<R, W, L>), grid, block, (L) ? s->lds_bytes : 0u, nullptr, s->S, s->plan, d_rays, n, seed, oh, orc, cursor, d_work)
+        const int variant = (recs ? 4 : 0) | (work ? 2 : 0) | (s->extend_lds ? 1 : 0);
+        switch (variant) {
+            case 0: RT_LAUNCH_TRACE(false, false, false); break;
+            case 1: RT_LAUNCH_TRACE(false, false, true); break;
+            case 2: RT_LAUNCH_TRACE(false, true, false); break;
+            case 3: RT_LAUNCH_TRACE(false, true, true); break;
+            case 4: RT_LAUNCH_TRACE(true, false, false); break;
+            case 5: RT_LAUNCH_TRACE(true, false, true); break;
+            case 6: RT_LAUNCH_TRACE(true, true, false); break;
+            default: RT_LAUNCH_TRACE(true, true, true); break;
         }
+#undef RT_LAUNCH_TRACE
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e1, nullptr));
         HIP_TRY(hipDeviceSynchronize());
