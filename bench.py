@@ -32,18 +32,31 @@ from raytracer_amd import abi, assets, lib  # noqa: E402
 from raytracer_amd.distributed import allreduce_accum  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
-# bytes read per visited entry beyond the 32-byte entry itself (sizeof of the table rows in include/rt/abi.h)
-ROW_BYTES = {"inner": 0, "sphere": 40, "msphere": 80, "rect": 56, "box6": 56, "triangle": 80, "xf_enter": 72, "xf_exit": 72,
-             "medium": 24}
-RAY_IN_BYTES = 7 * 8 + 4   # o, d, tm columns + queue index
-HIT_OUT_BYTES = 8 + 4 + 4  # t, entry, side/wrapper
+# Algorithmic bytes of one closest-hit query: 64 (ray in) + 32 per stream entry fetched + the f64 row of every
+# primitive tested + 32 (hit out). Rows: sphere 40, moving sphere 72, rect 48, box 56, triangle 80 bytes
+# (geometry + material id); wrapper and medium entries are charged their 32-byte entry only.
+ROW_BYTES = {"inner": 0, "sphere": 40, "msphere": 72, "rect": 48, "box6": 56, "triangle": 80, "xf_enter": 0, "xf_exit": 0,
+             "medium": 0}
+RAY_IN_BYTES = 64
+HIT_OUT_BYTES = 32
 
 WORKLOADS = {
     "final": dict(scene=9, width=800, height=800, name="Next Week final scene 800x800 (BASELINE configs[3])"),
     "cornell": dict(scene=7, width=600, height=600, name="Cornell box 600x600 (BASELINE configs[1])"),
     "smoke": dict(scene=8, width=600, height=600, name="Cornell smoke 600x600 (BASELINE configs[2])"),
     "weekend": dict(scene=1, width=1200, height=800, name="Weekend random spheres 1200x800 (BASELINE configs[0])"),
+    "mesh": dict(scene=12, width=3840, height=2160, n_triangles=10_000_000,
+                 name="Kaleidoscope + 10M synthetic triangles 3840x2160 (BASELINE configs[4])"),
 }
+
+
+def scene_kwargs(wl):
+    kw = {}
+    if wl["scene"] in (6, 9):
+        kw["image"] = assets.earthmap()
+    if "n_triangles" in wl:
+        kw["n_triangles"] = wl["n_triangles"]
+    return kw
 
 
 def algorithmic_bytes(rays, work):
@@ -55,7 +68,7 @@ def cpu_baseline(wl, spp, threads):
     samples per pixel, `threads` std::threads splitting columns as src/main.rs:193-195 does."""
     import oracle
     o = oracle.get()
-    kw = dict(image=assets.earthmap()) if wl["scene"] in (6, 9) else {}
+    kw = scene_kwargs(wl)
     sc = o.api.scene_build(wl["scene"], **kw)
     su = o.api.scene_setup(wl["scene"])
     cam = o.api.camera(su)
@@ -93,8 +106,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     L = lib.get()
-    kw = dict(image=assets.earthmap()) if wl["scene"] in (6, 9) else {}
-    hs = lib.HostScene.build(wl["scene"], **kw)
+    hs = lib.HostScene.build(wl["scene"], **scene_kwargs(wl))
     ds = lib.DeviceScene(hs)
     su = L.host.scene_setup(wl["scene"])
     cam = L.host.camera(su)
@@ -141,6 +153,9 @@ def main():
         wst, work = ds.render_work(cam, lib.make_params(W, H, s0, s0 + S, bg, samples_per_batch=S), scratch.data_ptr(), stream)
         bytes_per_ray = algorithmic_bytes(wst.rays, work) / max(1, wst.rays)
         launches = args.steps * 50
+        d = hs.desc
+        table_bytes = int(32 * d.n_nodes + 40 * d.n_spheres + 80 * d.n_msphere + 56 * d.n_rects + 56 * d.n_boxes + 80 * d.n_triangles +
+                          72 * d.n_xforms + 24 * d.n_media)
         achieved = rays * bytes_per_ray / (ms_extend * 1e-3) / 1e9 if ms_extend > 0 else 0.0
         out = {
             "metric": "path samples/s", "value": samples_total / elapsed, "unit": "samples/s", "n_gpus": world,
@@ -153,9 +168,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_ray": bytes_per_ray, "entries_per_ray": work["entries"] / max(1, wst.rays),
+                         "visits_per_ray": {k: round(work[k] / max(1, wst.rays), 4) for k in ROW_BYTES},
                          "ms_extend_per_step": ms_extend / args.steps, "ms_shade_per_step": ms_shade / args.steps,
                          "avg_launch_ms": ms_extend / launches,
-                         "note": "scene tables (<2 MiB) are cache resident: the kernel is f64-VALU/latency bound, not HBM bound"},
+                         "tables_in_lds": bool(table_bytes <= 144 * 1024), "table_bytes": table_bytes,
+                         "note": ("scene tables are staged in LDS: the kernel is f64-VALU / latency bound, HBM only carries the ray records"
+                                  if table_bytes <= 144 * 1024 else "scene tables are read from HBM / L2")},
         }
         if args.cpu_spp > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_spp, args.cpu_threads)

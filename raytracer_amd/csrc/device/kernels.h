@@ -139,6 +139,10 @@ RT_D SceneT<true> stage_scene(const DevScene& S, const LdsPlan& plan) {
 #define RT_REFILL_LANES 32
 #endif
 constexpr uint32_t REFILL_LANES = RT_REFILL_LANES;  // refill when at least this many lanes are idle
+#ifndef RT_RAY_CHUNK
+#define RT_RAY_CHUNK 256
+#endif
+constexpr uint32_t RAY_CHUNK = RT_RAY_CHUNK;  // rays a wave reserves per atomic while the pool is large
 
 template <bool COUNT, class SC, class IO>
 RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
@@ -151,6 +155,8 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
     uint32_t max_active = (n + total_waves - 1u) / total_waves;
     max_active = max_active < 8u ? 8u : (max_active > 64u ? 64u : max_active);
     const uint32_t refill_at = REFILL_LANES < max_active ? REFILL_LANES : max_active;
+    const uint32_t chunk = n / total_waves >= 4u * RAY_CHUNK ? RAY_CHUNK : 0u;
+    uint32_t c_next = 0u, c_end = 0u;
     Walker<COUNT> w;
     w.done = true;
     typename IO::Ray ray;
@@ -171,16 +177,25 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
             }
             if (!exhausted && room > 0u) {
                 const uint32_t my_rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
+                // rays come from the wave's reserved range [c_next, c_end); when it runs short, one atomic
+                // reserves the missing rays plus (with many rays in the pool) a whole chunk for later refills
+                const uint32_t avail = c_end - c_next;
                 uint32_t base = 0u;
-                if (lane == 0u) base = atomicAdd(cursor, room);
-                base = __shfl(base, 0, 64);
-                if (!busy && my_rank < room && base + my_rank < n) {
-                    index = base + my_rank;
+                if (avail < room) {
+                    const uint32_t want = room - avail > chunk ? room - avail : chunk;
+                    if (lane == 0u) base = atomicAdd(cursor, want);
+                    base = __shfl(base, 0, 64);
+                    c_end = base + want;
+                }
+                const uint32_t mine = my_rank < avail ? c_next + my_rank : base + (my_rank - avail);
+                if (!busy && my_rank < room && mine < n) {
+                    index = mine;
                     io.fetch(index, ray);
                     w.init(S, ray.o, ray.d, ray.tm, ray.tmin, ray.tmax);
                     busy = true;
                 }
-                exhausted = base + room >= n;
+                c_next = avail < room ? base + (room - avail) : c_next + room;
+                exhausted = c_next >= n;
             }
         }
         if (__ballot(busy) == 0ull) {

@@ -318,6 +318,12 @@ RT_D bool sphere_boundary(PS s, const Seg& g, double& t1, double& t2, uint32_t& 
     return true;
 }
 
+#ifdef RT_DIAG_WAVE
+// Diagnostic build (tools/diag_util.py): the work counters count wave-level executions of each entry kind (one
+// lane per wave counts) instead of lanes, which gives the lane utilisation of every phase of the loop.
+RT_D bool diag_first_lane() { return (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1; }
+#endif
+
 // ---- the walk ---------------------------------------------------------------------
 // State of one closest-hit query, advanced in two kinds of steps so that a wave can keep its lanes together:
 // box_run() consumes box entries until the lane stands on a non-box entry (or the query is finished), leaf()
@@ -394,7 +400,11 @@ struct Walker {
                 continue;
             }
             load_node(S.nodes + i, na, nb);
+#ifdef RT_DIAG_WAVE
+            if (COUNT && (nb.z & 15u) == RT_N_INNER && diag_first_lane()) { work->entries++; work->prim[RT_N_INNER]++; }
+#else
             if (COUNT) { work->entries++; work->prim[nb.z & 15u]++; }
+#endif
             if ((nb.z & 15u) != RT_N_INNER) return;
             i = box_hit(na, nb, g, tmin, best.t) ? i + 1u : nb.w;
         }
@@ -405,9 +415,15 @@ struct Walker {
         const uint32_t meta = nb.z;
         const uint32_t kind = meta & 15u;
         const uint32_t idx = meta >> 4;
+#ifdef RT_DIAG_WAVE
+#define RT_DIAG_LEAF(k) if (COUNT && diag_first_lane()) { work->entries++; work->prim[k]++; }
+#else
+#define RT_DIAG_LEAF(k)
+#endif
         switch (kind) {
             case RT_N_SPHERE:
-            case RT_N_MSPHERE: {  // one code path: a moving sphere is a sphere about center(r.tm) (src/hittable.rs:216)
+            case RT_N_MSPHERE: {
+                RT_DIAG_LEAF(RT_N_SPHERE)  // one code path: a moving sphere is a sphere about center(r.tm) (src/hittable.rs:216)
                 V3 c;
                 double r;
                 if (kind == RT_N_SPHERE) { const auto s = S.spheres + idx; c = v3p(s->c); r = s->r; }
@@ -417,22 +433,26 @@ struct Walker {
                 break;
             }
             case RT_N_RECT: {
+                RT_DIAG_LEAF(RT_N_RECT)
                 double t;
                 if (rect_hit(S.rects + idx, g, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
                 break;
             }
             case RT_N_BOX6: {
+                RT_DIAG_LEAF(RT_N_BOX6)
                 uint32_t side = 0u;
                 double t = best.t;
                 if (box6_hit(S.boxes + idx, g, tmin, t, side)) { best.t = t; best.ref = meta; best.aux = side | (cur_xf << 8); }
                 break;
             }
             case RT_N_TRIANGLE: {
+                RT_DIAG_LEAF(RT_N_TRIANGLE)
                 double t;
                 if (triangle_hit(S.triangles + idx, g.o, g.d, tmin, best.t, t)) { best.t = t; best.ref = meta; best.aux = cur_xf << 8; }
                 break;
             }
             case RT_N_XF_ENTER: {
+                RT_DIAG_LEAF(RT_N_XF_ENTER)
                 const auto x = S.xforms + idx;
                 V3 o = g.o, d = g.d;
                 xf_apply(x, o, d);
@@ -442,6 +462,7 @@ struct Walker {
                 break;
             }
             case RT_N_XF_EXIT: {
+                RT_DIAG_LEAF(RT_N_XF_EXIT)
                 // back in the parent's space: its ray is the stored world ray pushed through the parent's chain
                 const auto x = S.xforms + idx;
                 const uint32_t depth = x->depth;
@@ -453,13 +474,16 @@ struct Walker {
                 break;
             }
             default: {  // RT_N_MEDIUM, ConstantMedium::hit src/constant_medium.rs:34-89 (mode is 0 here)
+                RT_DIAG_LEAF(RT_N_MEDIUM)
                 const uint32_t first = S.nodes[i + 1u].meta;
                 if (nb.w == i + 2u && (first & 15u) == RT_N_SPHERE) {
                     // boundary is one sphere: both queries from one quadratic
                     double t1 = 0.0, t2 = 0.0;
                     uint32_t queries;
                     const bool inside = sphere_boundary(S.spheres + (first >> 4), g, t1, t2, queries);
+#ifndef RT_DIAG_WAVE
                     if (COUNT) { work->entries += queries; work->prim[RT_N_SPHERE] += queries; }
+#endif
                     if (inside) resolve_medium(S, key, meta, t1, t2);
                     i = nb.w;
                 } else {
