@@ -34,6 +34,10 @@ struct PathState {
 };
 
 // 16-byte loads/stores of a record (global_load_dwordx4 / global_store_dwordx4)
+// slot value of a padding record: the shade kernel reserves output records in chunks and pads what a wave did
+// not use; extend and shade skip such records
+constexpr uint32_t DEAD_SLOT = 0xFFFFFFFFu;
+
 RT_D void load_ray64(const RayRec* r, V3& o, V3& d, double& tm, uint32_t& slot) {
     const double2* p = reinterpret_cast<const double2*>(r);
     const double2 a = p[0], b = p[1], c = p[2];
@@ -143,6 +147,18 @@ constexpr uint32_t REFILL_LANES = RT_REFILL_LANES;  // refill when at least this
 #define RT_RAY_CHUNK 256
 #endif
 constexpr uint32_t RAY_CHUNK = RT_RAY_CHUNK;  // rays a wave reserves per atomic while the pool is large
+#ifndef RT_RAY_MIN_CHUNKS
+#define RT_RAY_MIN_CHUNKS 4
+#endif
+constexpr uint32_t RAY_MIN_CHUNKS = RT_RAY_MIN_CHUNKS;  // ... "large" = at least this many chunks per wave
+#ifndef RT_OUT_CHUNK
+#define RT_OUT_CHUNK 256
+#endif
+constexpr uint32_t OUT_CHUNK = RT_OUT_CHUNK;  // output records a shading wave reserves per atomic while there are many rays
+#ifndef RT_OUT_MIN_CHUNKS
+#define RT_OUT_MIN_CHUNKS 2
+#endif
+constexpr uint32_t OUT_MIN_CHUNKS = RT_OUT_MIN_CHUNKS;  // ... "many" = at least this many chunks of input per wave
 
 template <bool COUNT, class SC, class IO>
 RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
@@ -155,7 +171,7 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
     uint32_t max_active = (n + total_waves - 1u) / total_waves;
     max_active = max_active < 8u ? 8u : (max_active > 64u ? 64u : max_active);
     const uint32_t refill_at = REFILL_LANES < max_active ? REFILL_LANES : max_active;
-    const uint32_t chunk = n / total_waves >= 4u * RAY_CHUNK ? RAY_CHUNK : 0u;
+    const uint32_t chunk = n / total_waves >= RAY_MIN_CHUNKS * RAY_CHUNK ? RAY_CHUNK : 0u;
     uint32_t c_next = 0u, c_end = 0u;
     Walker<COUNT> w;
     w.done = true;
@@ -190,9 +206,10 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
                 const uint32_t mine = my_rank < avail ? c_next + my_rank : base + (my_rank - avail);
                 if (!busy && my_rank < room && mine < n) {
                     index = mine;
-                    io.fetch(index, ray);
-                    w.init(S, ray.o, ray.d, ray.tm, ray.tmin, ray.tmax);
-                    busy = true;
+                    if (io.fetch(index, ray)) {
+                        w.init(S, ray.o, ray.d, ray.tm, ray.tmin, ray.tmax);
+                        busy = true;
+                    }
                 }
                 c_next = avail < room ? base + (room - avail) : c_next + room;
                 exhausted = c_next >= n;
@@ -231,11 +248,12 @@ struct TraceIO {
         RayAoS rs;
     };
     RT_D uint32_t n() const { return (uint32_t)n_rays; }
-    RT_D void fetch(uint32_t i, Ray& r) const {
+    RT_D bool fetch(uint32_t i, Ray& r) const {
         const RtRay* q = rays + i;
         r.o = v3p(q->o); r.d = v3p(q->d); r.tm = q->tm; r.tmin = q->tmin; r.tmax = q->tmax;
         r.key.seed = seed; r.key.pixel = q->pixel; r.key.sample = q->sample; r.key.bounce = q->bounce;
         r.rs.r = q;
+        return true;
     }
     template <class SC>
     RT_D void store(const SC& S, uint32_t i, const Ray& r, const Cand& best) const {
@@ -321,11 +339,12 @@ struct ExtendIO {
         RayRecRef rs;
     };
     RT_D uint32_t n() const { return count; }
-    RT_D void fetch(uint32_t i, Ray& r) const {
+    RT_D bool fetch(uint32_t i, Ray& r) const {  // false: a padding record, no ray
         r.rs.r = recs + i;
         uint32_t slot;
         load_ray64(recs + i, r.o, r.d, r.tm, slot);
         r.key.seed = seed; r.key.pixel = slot % npix; r.key.sample = sample0 + slot / npix; r.key.bounce = bounce;
+        return slot != DEAD_SLOT;
     }
     template <class SC>
     RT_D void store(const SC&, uint32_t i, const Ray&, const Cand& best) const {
@@ -364,21 +383,28 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
     const RayRec* recs = P.rec[cur];
     RayRec* next = P.rec[cur ^ 1u];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(ray_total, (unsigned long long)n);
+        if (bounce == 0u) atomicAdd(ray_total, (unsigned long long)n);  // later bounces: counted as survivors below
         counts[2] = 0u;  // ray cursor of the next extend launch
     }
     const uint32_t stride = gridDim.x * SHADE_BLOCK;
+    const uint32_t lane = threadIdx.x & 63u;
+    // Output records are reserved in chunks: [o_next, o_end) is what the wave still holds (wave-uniform).
+    const uint32_t total_waves = gridDim.x * (SHADE_BLOCK / 64u);
+    const uint32_t chunk = n / total_waves >= OUT_MIN_CHUNKS * OUT_CHUNK ? OUT_CHUNK : 0u;
+    uint32_t o_next = 0u, o_end = 0u, survivors = 0u;
     // every lane of a wave runs the same number of iterations so that the ballot below sees whole waves
     const uint32_t n_round = (n + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_round; i += stride) {
         bool alive = false;
         V3 no = v3(0.0, 0.0, 0.0), nd = no, T = no;
         double tm = 0.0;
-        uint32_t slot = 0u;
+        uint32_t slot = DEAD_SLOT;
+        V3 o = no, d = no;
         if (i < n) {
-            V3 o, d;
             load_ray64(recs + i, o, d, tm, slot);
             load_throughput(recs + i, T);
+        }
+        if (slot != DEAD_SLOT) {
             const uint4 h = *reinterpret_cast<const uint4*>(P.hit + i);
             Cand best;
             best.t = __hiloint2double((int)h.y, (int)h.x); best.ref = h.z; best.aux = h.w;
@@ -409,17 +435,28 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
                 }
             }
         }
-        // compaction: one atomic per wave, survivors of a wave land in consecutive records
+        // compaction: survivors of a wave land in consecutive records of the wave's reserved range; when the
+        // range runs short one atomic reserves the missing records plus (with many rays) a whole chunk
         const unsigned long long mask = __ballot(alive);
         if (mask) {
-            const uint32_t lane = threadIdx.x & 63u;
-            const int leader = __ffsll((long long)mask) - 1;
+            const uint32_t cnt = (uint32_t)__popcll(mask);
+            const uint32_t avail = o_end - o_next;
             uint32_t base = 0u;
-            if ((int)lane == leader) base = atomicAdd(next_count, (uint32_t)__popcll(mask));
-            base = __shfl(base, leader, 64);
-            if (alive) store_ray(next + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), no, nd, tm, slot, T);
+            if (avail < cnt) {
+                const uint32_t want = cnt - avail > chunk ? cnt - avail : chunk;
+                if (lane == 0u) base = atomicAdd(next_count, want);
+                base = __shfl(base, 0, 64);
+                o_end = base + want;
+            }
+            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if (alive) store_ray(next + (rank < avail ? o_next + rank : base + (rank - avail)), no, nd, tm, slot, T);
+            o_next = avail < cnt ? base + (cnt - avail) : o_next + cnt;
+            survivors += cnt;
         }
     }
+    // pad the unused part of the last chunk
+    for (uint32_t k = o_next + lane; k < o_end; k += 64u) next[k].slot = DEAD_SLOT;
+    if (lane == 0u && survivors) atomicAdd(ray_total, (unsigned long long)survivors);
 }
 
 template <bool LDS>

@@ -174,6 +174,10 @@ void free_workspace(Workspace& w) {
     w = Workspace();
 }
 
+uint64_t shade_padding(const RtScene* s) {
+    return (uint64_t)s->grid_shade * (rtd::SHADE_BLOCK / 64u) * rtd::OUT_CHUNK;
+}
+
 int ensure_workspace(RtScene* s, uint64_t n_slots) {
     Workspace& w = s->ws;
     if (!w.counts) {
@@ -182,12 +186,15 @@ int ensure_workspace(RtScene* s, uint64_t n_slots) {
     }
     if (w.cap_slots >= n_slots) return RT_OK;
     if (w.base) { HIP_TRY(hipFree(w.base)); w.base = nullptr; w.cap_slots = 0; }
-    const uint64_t bytes = n_slots * (2 * sizeof(rtd::RayRec) + sizeof(rtd::HitSlot) + 3 * sizeof(double));
+    // The shade kernel reserves output records in chunks and pads what a wave leaves unused, so the record and
+    // hit arrays can grow past the number of paths by one chunk per shading wave.
+    const uint64_t n_recs = n_slots + shade_padding(s);
+    const uint64_t bytes = n_recs * (2 * sizeof(rtd::RayRec) + sizeof(rtd::HitSlot)) + n_slots * 3 * sizeof(double);
     HIP_TRY(hipMalloc((void**)&w.base, bytes));
     char* p = w.base;
-    w.P.rec[0] = reinterpret_cast<rtd::RayRec*>(p); p += n_slots * sizeof(rtd::RayRec);
-    w.P.rec[1] = reinterpret_cast<rtd::RayRec*>(p); p += n_slots * sizeof(rtd::RayRec);
-    w.P.hit = reinterpret_cast<rtd::HitSlot*>(p); p += n_slots * sizeof(rtd::HitSlot);
+    w.P.rec[0] = reinterpret_cast<rtd::RayRec*>(p); p += n_recs * sizeof(rtd::RayRec);
+    w.P.rec[1] = reinterpret_cast<rtd::RayRec*>(p); p += n_recs * sizeof(rtd::RayRec);
+    w.P.hit = reinterpret_cast<rtd::HitSlot*>(p); p += n_recs * sizeof(rtd::HitSlot);
     w.P.lr = reinterpret_cast<double*>(p); p += n_slots * sizeof(double);
     w.P.lg = reinterpret_cast<double*>(p); p += n_slots * sizeof(double);
     w.P.lb = reinterpret_cast<double*>(p);
@@ -214,7 +221,8 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     uint32_t spb = p->samples_per_batch;
     if (spb == 0) spb = (uint32_t)std::max<uint64_t>(1, kDefaultSlotTarget / npix);
     spb = std::min(spb, total);
-    if (npix * spb >= (1ull << 32)) spb = (uint32_t)(((1ull << 32) - 1) / npix);
+    const uint64_t max_slots = (1ull << 32) - 2 - shade_padding(s);  // record indices and counts are 32-bit
+    if (npix * spb > max_slots) spb = (uint32_t)(max_slots / npix);
     if (int rc = ensure_workspace(s, npix * spb)) return rc;
     Workspace& w = s->ws;
 
@@ -364,7 +372,10 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         oe = s->shade_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, rtd::k_shade<true>, rtd::SHADE_BLOCK, s->lds_bytes_shade)
                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, rtd::k_shade<false>, rtd::SHADE_BLOCK, 0);
         if (oe != hipSuccess || shade_per_cu < 1) shade_per_cu = 1;
-        s->grid_shade = s->n_cus * (uint32_t)shade_per_cu * 4u;
+#ifndef RT_SHADE_GRID_MULT
+#define RT_SHADE_GRID_MULT 1
+#endif
+        s->grid_shade = s->n_cus * (uint32_t)shade_per_cu * RT_SHADE_GRID_MULT;
         if ((rc = upload(s, d->nodes, d->n_nodes, &s->S.nodes))) break;
         if ((rc = upload(s, d->spheres, d->n_spheres, &s->S.spheres))) break;
         if ((rc = upload(s, d->msphere, d->n_msphere, &s->S.msphere))) break;
