@@ -168,19 +168,7 @@ RT_D bool box_hit(const uint4 na, const uint4 nb, const Seg& g, double tmin, dou
 }
 
 // ---- primitives -----------------------------------------------------------------
-// Every primitive test below evaluates the reference's expressions exactly when it may succeed. In front of
-// the expensive part (division, f64 sqrt) sits a screen that proves failure from cheaper approximations with
-// error margins orders of magnitude above their rounding error; it can only say "cannot hit", NaN or infinite
-// intermediates make its comparisons false and fall through to the exact test.
-#ifndef RT_SCREEN_SPHERE
-#define RT_SCREEN_SPHERE 1
-#endif
-#ifndef RT_SCREEN_RECT
-#define RT_SCREEN_RECT 1
-#endif
-constexpr double SCREEN_T = 0x1.0p-46;   // relative margin on an approximate quotient (its error is < 2^-50)
-constexpr double SCREEN_P = 0x1.0p-44;   // relative margin on o + t*d built from it
-constexpr double SCREEN_ABS = 1e-290;    // covers the subnormal range
+// Every primitive test below evaluates the reference's expressions in the reference's order.
 
 // Sphere::hit src/hittable.rs:72-113 (strict t_min < t < t_max). `a` = d . d > 0.
 RT_D bool sphere_roots(V3 oc, V3 d, double a, double r, double tmin, double tmax, double& t_out) {
@@ -188,17 +176,6 @@ RT_D bool sphere_roots(V3 oc, V3 d, double a, double r, double tmin, double tmax
     const double c = squared_length(oc) - r * r;
     const double discriminant = half_b * half_b - a * c;
     if (discriminant > 0.0) {
-        if (RT_SCREEN_SPHERE && discriminant > 1e-30 && discriminant < 1e30) {
-            // screen: temp = n / a lies in (tmin, tmax) only if n lies in (tmin*a, tmax*a); f32 sqrt is within 2^-22
-            const double rs = (double)sqrtf((float)discriminant);
-            const double n1 = -half_b - rs, n2 = -half_b + rs;
-            const double lo = tmin * a, hi = tmax * a;
-            const double m = rs * 0x1.0p-20 + (fabs(half_b) + rs) * SCREEN_T + SCREEN_ABS;
-            const double mlo = m + fabs(lo) * SCREEN_T, mhi = m + fabs(hi) * SCREEN_T;
-            const bool out1 = n1 - mhi > hi || n1 + mlo < lo;
-            const bool out2 = n2 - mhi > hi || n2 + mlo < lo;
-            if (out1 && out2) return false;
-        }
         const double root = sqrt(discriminant);
         double temp = (-half_b - root) / a;
         if (temp < tmax && temp > tmin) { t_out = temp; return true; }
@@ -219,20 +196,9 @@ RT_D V3 msphere_center(PM s, double time) {
 }
 
 // XYRect/XZRect/YZRect::hit src/aarect.rs:30-39, 81-90, 132-141: plane, then inclusive bounds.
-// (ok, dk) = ray origin/direction along the plane normal, (oa, da), (ob, db) in the plane; ik = 1/dk as rounded
-// by Seg (used by the screen only).
-RT_D bool rect_t(double k, double a0, double a1, double b0, double b1, double ok, double dk, double ik, double oa, double da,
+// (ok, dk) = ray origin/direction along the plane normal, (oa, da), (ob, db) in the plane.
+RT_D bool rect_t(double k, double a0, double a1, double b0, double b1, double ok, double dk, double oa, double da,
                  double ob, double db, double tmin, double tmax, double& t_out) {
-    if (RT_SCREEN_RECT) {
-        const double ta = (k - ok) * ik;
-        const double et = fabs(ta) * SCREEN_T + SCREEN_ABS;
-        if (ta + et < tmin || ta - et > tmax) return false;
-        const double pa = ta * da, pb = ta * db;
-        const double aa = oa + pa, ab = ob + pb;
-        const double ea = (fabs(oa) + fabs(pa)) * SCREEN_P + SCREEN_ABS;
-        const double eb = (fabs(ob) + fabs(pb)) * SCREEN_P + SCREEN_ABS;
-        if (aa + ea < a0 || aa - ea > a1 || ab + eb < b0 || ab - eb > b1) return false;
-    }
     const double t = (k - ok) / dk;
     if (t < tmin || t > tmax) return false;
     const double a = oa + t * da;
@@ -246,11 +212,11 @@ template <class PR>
 RT_D bool rect_hit(PR r, const Seg& g, double tmin, double tmax, double& t_out) {
     const uint32_t axis = r->axis;
     const V3 o = g.o, d = g.d;
-    double ok, dk, ik, oa, da, ob, db;
-    if (axis == 0u) { ok = o.z; dk = d.z; ik = g.invd.z; oa = o.x; da = d.x; ob = o.y; db = d.y; }
-    else if (axis == 1u) { ok = o.y; dk = d.y; ik = g.invd.y; oa = o.x; da = d.x; ob = o.z; db = d.z; }
-    else { ok = o.x; dk = d.x; ik = g.invd.x; oa = o.y; da = d.y; ob = o.z; db = d.z; }
-    return rect_t(r->k, r->a0, r->a1, r->b0, r->b1, ok, dk, ik, oa, da, ob, db, tmin, tmax, t_out);
+    double ok, dk, oa, da, ob, db;
+    if (axis == 0u) { ok = o.z; dk = d.z; oa = o.x; da = d.x; ob = o.y; db = d.y; }
+    else if (axis == 1u) { ok = o.y; dk = d.y; oa = o.x; da = d.x; ob = o.z; db = d.z; }
+    else { ok = o.x; dk = d.x; oa = o.y; da = d.y; ob = o.z; db = d.z; }
+    return rect_t(r->k, r->a0, r->a1, r->b0, r->b1, ok, dk, oa, da, ob, db, tmin, tmax, t_out);
 }
 
 // Box6::hit -> HittableList::hit over the six sides in src/box6.rs:22-71 order, each against the
@@ -258,15 +224,15 @@ RT_D bool rect_hit(PR r, const Seg& g, double tmin, double tmax, double& t_out) 
 template <class PB>
 RT_D bool box6_hit(PB b, const Seg& g, double tmin, double& tmax, uint32_t& side_out) {
     const V3 p0 = v3p(b->p0), p1 = v3p(b->p1);
-    const V3 o = g.o, d = g.d, iv = g.invd;
+    const V3 o = g.o, d = g.d;
     bool any = false;
     double t;
-    if (rect_t(p1.z, p0.x, p1.x, p0.y, p1.y, o.z, d.z, iv.z, o.x, d.x, o.y, d.y, tmin, tmax, t)) { tmax = t; side_out = 0u; any = true; }
-    if (rect_t(p0.z, p0.x, p1.x, p0.y, p1.y, o.z, d.z, iv.z, o.x, d.x, o.y, d.y, tmin, tmax, t)) { tmax = t; side_out = 1u; any = true; }
-    if (rect_t(p1.y, p0.x, p1.x, p0.z, p1.z, o.y, d.y, iv.y, o.x, d.x, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 2u; any = true; }
-    if (rect_t(p0.y, p0.x, p1.x, p0.z, p1.z, o.y, d.y, iv.y, o.x, d.x, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 3u; any = true; }
-    if (rect_t(p1.x, p0.y, p1.y, p0.z, p1.z, o.x, d.x, iv.x, o.y, d.y, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 4u; any = true; }
-    if (rect_t(p0.x, p0.y, p1.y, p0.z, p1.z, o.x, d.x, iv.x, o.y, d.y, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 5u; any = true; }
+    if (rect_t(p1.z, p0.x, p1.x, p0.y, p1.y, o.z, d.z, o.x, d.x, o.y, d.y, tmin, tmax, t)) { tmax = t; side_out = 0u; any = true; }
+    if (rect_t(p0.z, p0.x, p1.x, p0.y, p1.y, o.z, d.z, o.x, d.x, o.y, d.y, tmin, tmax, t)) { tmax = t; side_out = 1u; any = true; }
+    if (rect_t(p1.y, p0.x, p1.x, p0.z, p1.z, o.y, d.y, o.x, d.x, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 2u; any = true; }
+    if (rect_t(p0.y, p0.x, p1.x, p0.z, p1.z, o.y, d.y, o.x, d.x, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 3u; any = true; }
+    if (rect_t(p1.x, p0.y, p1.y, p0.z, p1.z, o.x, d.x, o.y, d.y, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 4u; any = true; }
+    if (rect_t(p0.x, p0.y, p1.y, p0.z, p1.z, o.x, d.x, o.y, d.y, o.z, d.z, tmin, tmax, t)) { tmax = t; side_out = 5u; any = true; }
     return any;
 }
 
