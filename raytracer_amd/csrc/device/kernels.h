@@ -375,6 +375,13 @@ __global__ void __launch_bounds__(EXT_BLOCK, RT_EXTEND_WAVES) k_extend(DevScene 
 // ---- shade ---------------------------------------------------------------------------------
 // The body of ray_color after world.hit (src/color.rs:42-62), unrolled from recursion into
 // L += T * emitted; T *= attenuation. Survivors go to the other record array.
+// L += add. The columns start at +0.0 and x + (+-0.0) == x bit for bit for every x but -0.0, which a sum of
+// products of non-negative colours never is: an all-zero term (black background, black emitter) is skipped.
+RT_D void add_radiance(const PathState& P, uint32_t slot, V3 add) {
+    if (add.x == 0.0 && add.y == 0.0 && add.z == 0.0) return;
+    P.lr[slot] += add.x; P.lg[slot] += add.y; P.lb[slot] += add.z;
+}
+
 template <class SC>
 RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
                     unsigned long long* __restrict__ ray_total) {
@@ -409,8 +416,7 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
             Cand best;
             best.t = __hiloint2double((int)h.y, (int)h.x); best.ref = h.z; best.aux = h.w;
             if (best.ref == RT_MISS) {
-                const V3 add = elemul(T, v3p(C.bg));  // src/color.rs:41-43
-                P.lr[slot] += add.x; P.lg[slot] += add.y; P.lb[slot] += add.z;
+                add_radiance(P, slot, elemul(T, v3p(C.bg)));  // src/color.rs:41-43
             } else {
                 const auto M = S.materials + hit_material(S, best);
                 const uint32_t mkind = M->kind;
@@ -421,8 +427,7 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
                 V3 texv = v3(0.0, 0.0, 0.0);
                 if (textured) texv = texture_value(S, M->tex, rec.u, rec.v, rec.p);
                 if (mkind == RT_M_DIFFUSE_LIGHT) {  // emitted, :50 (zero for every other material)
-                    const V3 add = elemul(T, texv);
-                    P.lr[slot] += add.x; P.lg[slot] += add.y; P.lb[slot] += add.z;
+                    add_radiance(P, slot, elemul(T, texv));
                 }
                 rt::Rng rng;
                 rng.set_path(C.seed, slot % C.npix, C.sample0 + slot / C.npix, bounce, rt::RNG_SCATTER);

@@ -29,11 +29,11 @@ def main():
     osc = o.api.scene_build(sid, **kw)
     su = o.api.scene_setup(sid)
     cam = o.api.camera(su)
-    W = 400
+    W = 800
     H = int(W / su.aspect_ratio)
     p = o.make_params(W, H, 0, 8, list(su.background))
     t0 = time.time()
-    rays = o.harvest(osc, cam, p, n_paths=W * H * 4, max_rays=3_000_000, max_bounce=6)
+    rays = o.harvest(osc, cam, p, n_paths=W * H * 4, max_rays=14_000_000, max_bounce=6)
     print("harvested", len(rays), "rays in %.1f s" % (time.time() - t0), flush=True)
     for bounce_sel, name in ((rays["bounce"] == 0, "bounce 0"), (rays["bounce"] == 1, "bounce 1"), (rays["bounce"] >= 2, "bounce 2-6")):
         r = rays[bounce_sel]
