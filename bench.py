@@ -50,8 +50,8 @@ WORKLOADS = {
 }
 
 
-def scene_kwargs(wl):
-    kw = {}
+def scene_kwargs(wl, bvh="reference"):
+    kw = {"flags": abi.RT_SCENE_BVH_WIDEST_AXIS} if bvh == "widest" else {}
     if wl["scene"] in (6, 9):
         kw["image"] = assets.earthmap()
     if "n_triangles" in wl:
@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="final", choices=sorted(WORKLOADS))
     ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--bvh", default="reference", choices=["reference", "widest"],
+                    help="BVHNode split axis: the reference's random axis (src/bvh.rs:24) or the widest spread of box minima")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the CPU baseline run (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=8, help="the reference's own thread count (src/main.rs:189)")
     args = ap.parse_args()
@@ -106,7 +108,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     L = lib.get()
-    hs = lib.HostScene.build(wl["scene"], **scene_kwargs(wl))
+    hs = lib.HostScene.build(wl["scene"], **scene_kwargs(wl, args.bvh))
     ds = lib.DeviceScene(hs)
     su = L.host.scene_setup(wl["scene"])
     cam = L.host.camera(su)
@@ -161,7 +163,7 @@ def main():
             "metric": "path samples/s", "value": samples_total / elapsed, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl["name"], "width": W, "height": H, "spp_per_step_per_gpu": S, "max_depth": 50,
+            "config": {"workload": wl["name"], "width": W, "height": H, "spp_per_step_per_gpu": S, "max_depth": 50, "bvh": args.bvh,
                        "sharding": "sample ranges per rank, one RCCL all-reduce of the f32 accumulation buffer"},
             "mrays_per_s": rays * world / elapsed / 1e6 if world == 1 else None,
             "rays_per_sample": rays / (W * H * S * args.steps),

@@ -45,6 +45,10 @@ enum RtSceneId {                 /* the `match scene` of src/main.rs:65-162 */
 #define RT_SCENE_BVH_SHUTTER_TIMES 1u  /* random_scene: build the BVH over the shutter interval (0,1) instead of the
                                           reference's (0,0.1) (src/main.rs:315), so moving-sphere boxes bound them */
 
+#define RT_SCENE_BVH_WIDEST_AXIS 2u    /* every BVHNode splits along the axis on which its objects' box minima spread the
+                                          widest instead of the reference's random axis (src/bvh.rs:24): same closest
+                                          hits (up to exact ties in t), far fewer boxes visited on large meshes */
+
 typedef struct RtSceneOptions {
     uint32_t flags;
     uint32_t boxes_per_side;     /* final_scene ground grid (src/main.rs:591); 0 = 20 */

@@ -118,15 +118,18 @@ int orc_scene_build(int scene_id, uint64_t seed, const RtSceneOptions* opt, OrcS
     SceneOptions o;
     if (opt) {
         o.bvh_shutter_times = (opt->flags & RT_SCENE_BVH_SHUTTER_TIMES) != 0;
+        o.bvh_widest_axis = (opt->flags & RT_SCENE_BVH_WIDEST_AXIS) != 0;
         if (opt->boxes_per_side) o.boxes_per_side = opt->boxes_per_side;
         o.n_triangles = opt->n_triangles;
         o.image_rgb = opt->image_rgb; o.image_w = opt->image_width; o.image_h = opt->image_height;
     }
     cur_ctx = &s->ctx;
     tls.rng.set_scene(seed);
+    bvh_widest_axis = o.bvh_widest_axis;
     try {
         s->world = build_scene(scene_id, o);
-    } catch (const std::exception& e) { cur_ctx = nullptr; delete s; return fail(RT_E_INVALID, e.what()); }
+    } catch (const std::exception& e) { cur_ctx = nullptr; bvh_widest_axis = false; delete s; return fail(RT_E_INVALID, e.what()); }
+    bvh_widest_axis = false;
     cur_ctx = nullptr;
     if (!s->world) { delete s; return fail(RT_E_INVALID, "unknown scene id"); }
     *out = s;

@@ -878,10 +878,28 @@ inline bool box_less(const HitPtr& a, const HitPtr& b, int axis) {  // box_compa
     return box_a._min[axis] < box_b._min[axis];
 }
 
+// Split-axis policy (not in the reference): false = the reference's random axis, true = the axis on which the box
+// minima of the node's objects spread the widest (ties: the lowest axis).
+inline thread_local bool bvh_widest_axis = false;
+
+inline int widest_axis(const std::vector<HitPtr>& objects, size_t start, size_t end) {
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = std::numeric_limits<double>::infinity(); hi[a] = -lo[a]; }
+    for (size_t i = start; i < end; ++i) {
+        AABB b;
+        if (!objects[i]->bounding_box(0.0, 0.0, b)) throw std::runtime_error("no bounding box");
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b._min[a]); hi[a] = std::max(hi[a], b._min[a]); }
+    }
+    int best = 0;
+    for (int a = 1; a < 3; ++a) if (hi[a] - lo[a] > hi[best] - lo[best]) best = a;
+    return best;
+}
+
 inline std::shared_ptr<BVHNode> new_from_list(std::vector<HitPtr>& objects, size_t start, size_t end, double time0,
                                               double time1) {  // :17-91
     int axis = random_int(0, 2);
     size_t object_span = end - start;
+    if (bvh_widest_axis && object_span > 1) axis = widest_axis(objects, start, end);
     auto temp = std::make_shared<BVHNode>();
     if (object_span == 1) {
         temp->left = objects[start];

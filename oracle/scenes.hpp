@@ -8,6 +8,7 @@ namespace orc {
 
 struct SceneOptions {
     bool bvh_shutter_times = false;  // random_scene BVH over (0,1) instead of the reference's (0,0.1)
+    bool bvh_widest_axis = false;    // BVHNode split axis: widest spread of box minima instead of random
     uint32_t boxes_per_side = 20;    // src/main.rs:591
     uint64_t n_triangles = 0;        // synthetic triangle soup of scene 12
     const uint8_t* image_rgb = nullptr;
@@ -272,8 +273,8 @@ inline HitPtr kaleidoscope() {  // src/main.rs:740-765
 // Lambertian triangles in four layers behind the far end of the mirror tube.
 //   L = 4 layers at y = 20.5 + 0.5*l; G x G cells over x in [-8.5, 11.5],
 //   z in [-10.866, 9.134], G = ceil(sqrt(n / (2L))); per cell four corners
-//   (a,b) in (0,0),(1,0),(0,1),(1,1), each jittered by 0.2 cell in x and z and
-//   0.2 in y (draw order x, y, z), two triangles (p10,p01,p00) and (p01,p10,p11),
+//   (a,b) in (0,0),(1,0),(0,1),(1,1), each jittered by 0.2 cell in x, y and z
+//   (draw order x, y, z), two triangles (p10,p01,p00) and (p01,p10,p11),
 //   each with a palette material picked by random_int(0, 63).
 inline HitPtr kaleidoscope_mesh(const SceneOptions& o) {
     HittableList world;
@@ -293,7 +294,7 @@ inline HitPtr kaleidoscope_mesh(const SceneOptions& o) {
                 for (int b = 0; b < 2; ++b)
                     for (int a = 0; a < 2; ++a) {
                         double px = X0 + ((double)i + (double)a) * h + 0.2 * h * random_double(-1.0, 1.0);
-                        double py = yl + 0.2 * random_double(-1.0, 1.0);
+                        double py = yl + 0.2 * h * random_double(-1.0, 1.0);
                         double pz = Z0 + ((double)j + (double)b) * h + 0.2 * h * random_double(-1.0, 1.0);
                         c[a][b] = Point(px, py, pz);
                     }

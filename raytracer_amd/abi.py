@@ -127,6 +127,7 @@ class RtSceneSetup(C.Structure):
 
 
 RT_SCENE_BVH_SHUTTER_TIMES = 1
+RT_SCENE_BVH_WIDEST_AXIS = 2
 
 # numpy views of the per-ray structs (same layout, no padding surprises: all members are 4/8-byte aligned)
 RAY_DTYPE = np.dtype([("o", "<f8", 3), ("d", "<f8", 3), ("tm", "<f8"), ("tmin", "<f8"), ("tmax", "<f8"),

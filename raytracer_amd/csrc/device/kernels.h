@@ -75,6 +75,13 @@ struct RenderConst {
 };
 
 constexpr int BLOCK = 256;
+#ifndef RT_EXT_BLOCK_GLOBAL
+#define RT_EXT_BLOCK_GLOBAL 1024
+#endif
+#ifndef RT_EXTEND_WAVES_GLOBAL
+#define RT_EXTEND_WAVES_GLOBAL 4
+#endif
+constexpr int EXT_BLOCK_GLOBAL = RT_EXT_BLOCK_GLOBAL;  // extend when the tables stay in global memory
 constexpr int EXT_BLOCK = 768;    // extend: one 12-wave workgroup per CU sharing one LDS copy of the scene tables
 constexpr int TRACE_BLOCK = 512;  // rt_trace_*: also rebuilds the hit record, needs more registers per lane
 constexpr int SHADE_BLOCK = 512;  // shade: 8 waves per workgroup share the LDS copy of primitive / material / texture tables
@@ -357,7 +364,7 @@ struct ExtendIO {
 // counts[0], counts[1]: lengths of the two record arrays; counts[2]: the ray cursor of this launch (zero on
 // entry, reset by the shade launch that follows).
 template <bool COUNT, bool LDS>
-__global__ void __launch_bounds__(EXT_BLOCK, RT_EXTEND_WAVES) k_extend(DevScene S0, LdsPlan plan, RenderConst C, PathState P,
+__global__ void __launch_bounds__(LDS ? EXT_BLOCK : EXT_BLOCK_GLOBAL, LDS ? RT_EXTEND_WAVES : RT_EXTEND_WAVES_GLOBAL) k_extend(DevScene S0, LdsPlan plan, RenderConst C, PathState P,
                                                                        uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
                                                                        unsigned long long* __restrict__ work_out) {
     ExtendIO io;

@@ -49,11 +49,16 @@ struct SceneT {
 };
 using DevScene = SceneT<false>;
 
-RT_D void load_node(const RtNode* p, uint4& a, uint4& b) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    a = q[0]; b = q[1];
-}
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+RT_D void load_node(const RtNode* p, uint4& a, uint4& b) {
+    const u32x4* q = reinterpret_cast<const u32x4*>(p);
+    u32x4 x = q[0], y = q[1];
+    // Both halves are requested before either is used: one trip to L2 / HBM per entry instead of two dependent
+    // ones (left alone, the compiler postpones the box half until it has looked at the kind).
+    asm volatile("" : "+v"(x), "+v"(y));
+    a = make_uint4(x.x, x.y, x.z, x.w);
+    b = make_uint4(y.x, y.y, y.z, y.w);
+}
 RT_D void load_node(const RT_LDS RtNode* p, uint4& a, uint4& b) {
     const RT_LDS u32x4* q = reinterpret_cast<const RT_LDS u32x4*>(p);
     const u32x4 x = q[0], y = q[1];

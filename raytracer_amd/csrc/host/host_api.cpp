@@ -83,12 +83,17 @@ int rth_scene_build(int scene_id, uint64_t seed, const RtSceneOptions* opt, RtHo
         SceneOptions o;
         if (opt) {
             o.bvh_shutter_times = (opt->flags & RT_SCENE_BVH_SHUTTER_TIMES) != 0;
+            o.bvh_widest_axis = (opt->flags & RT_SCENE_BVH_WIDEST_AXIS) != 0;
             if (opt->boxes_per_side) o.boxes_per_side = opt->boxes_per_side;
             o.n_triangles = opt->n_triangles;
             o.image_rgb = opt->image_rgb; o.image_w = opt->image_width; o.image_h = opt->image_height;
         }
         SceneCtx ctx(seed);
         CtxScope scope(&ctx);
+        struct AxisPolicy {  // the split-axis policy applies to this build only, also when it throws
+            explicit AxisPolicy(bool widest) { g_bvh_widest_axis = widest; }
+            ~AxisPolicy() { g_bvh_widest_axis = false; }
+        } policy(o.bvh_widest_axis);
         HitPtr world = build_scene(scene_id, o);
         if (!world) return rt::set_error(RT_E_INVALID, "unknown scene id");
         *out = flatten_root(*world);

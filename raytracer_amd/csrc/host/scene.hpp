@@ -562,10 +562,28 @@ inline double box_key(const HitPtr& o, int axis) {
     return b._min[axis];
 }
 
+// Split-axis policy of the builder below. false: the reference's random axis. true: the axis on which the
+// box minima of the node's objects spread the widest (ties: the lowest axis).
+inline thread_local bool g_bvh_widest_axis = false;
+
+inline int widest_axis(const std::vector<HitPtr>& objects, size_t start, size_t end) {
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = std::numeric_limits<double>::infinity(); hi[a] = -lo[a]; }
+    for (size_t i = start; i < end; ++i) {
+        AABB b;
+        if (!objects[i]->bounding_box(0.0, 0.0, b)) throw std::runtime_error("object without a bounding box in BVHNode::new");
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b._min[a]); hi[a] = std::max(hi[a], b._min[a]); }
+    }
+    int best = 0;
+    for (int a = 1; a < 3; ++a) if (hi[a] - lo[a] > hi[best] - lo[best]) best = a;
+    return best;
+}
+
 inline std::shared_ptr<BVHNode> new_from_list(std::vector<HitPtr>& objects, size_t start, size_t end, double time0,
                                               double time1) {  // src/bvh.rs:17-91
-    const int axis = random_int(0, 2);  // drawn for every node, also span 1 and 2 (:24)
+    int axis = random_int(0, 2);  // drawn for every node, also span 1 and 2 (:24)
     const size_t span = end - start;
+    if (g_bvh_widest_axis && span > 1) axis = widest_axis(objects, start, end);
     auto node = std::make_shared<BVHNode>();
     if (span == 1) {
         node->left = node->right = objects[start];

@@ -267,7 +267,7 @@ static HitPtr kaleidoscope() {  // src/main.rs:740-765
 // jittered Lambertian triangles in four layers behind the far end of the mirror tube.
 //   layers l = 0..3 at y = 20.5 + 0.5 l; G x G cells over x in [-8.5, 11.5], z in [-10.866, 9.134],
 //   G = ceil(sqrt(n / 8)); per cell the corners (a, b) = (0,0), (1,0), (0,1), (1,1) are jittered by
-//   0.2 cell in x and z and by 0.2 in y (draw order x, y, z); two triangles (p10, p01, p00) and
+//   0.2 cell in x, y and z (draw order x, y, z); two triangles (p10, p01, p00) and
 //   (p01, p10, p11), each followed by its palette pick random_int(0, 63). The 64 palette colours are
 //   drawn first, Color::random(0.1, 0.95) each.
 static HitPtr kaleidoscope_mesh(const SceneOptions& o) {
@@ -289,7 +289,7 @@ static HitPtr kaleidoscope_mesh(const SceneOptions& o) {
                 for (int b = 0; b < 2; ++b) {
                     for (int a = 0; a < 2; ++a) {
                         const double px = X0 + ((double)i + (double)a) * h + 0.2 * h * random_double(-1.0, 1.0);
-                        const double py = yl + 0.2 * random_double(-1.0, 1.0);
+                        const double py = yl + 0.2 * h * random_double(-1.0, 1.0);
                         const double pz = Z0 + ((double)j + (double)b) * h + 0.2 * h * random_double(-1.0, 1.0);
                         c[a][b] = Point(px, py, pz);
                     }

