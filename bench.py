@@ -59,6 +59,18 @@ def scene_kwargs(wl, bvh="reference"):
     return kw
 
 
+def measured_traffic(workload, spp):
+    """HBM bytes per extend launch from the committed rocprofv3 counter passes (profiles/hbm_traffic.json), or
+    None when there is no measurement for this workload and batch size: counters cannot be read from inside a run."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path)).get(workload)
+    if not t or t.get("spp_per_step") != spp:
+        return None
+    return t["bytes_per_launch"]
+
+
 def algorithmic_bytes(rays, work):
     return rays * (RAY_IN_BYTES + HIT_OUT_BYTES) + 32 * work["entries"] + sum(ROW_BYTES[k] * work[k] for k in ROW_BYTES)
 
@@ -168,7 +180,8 @@ def main():
             "mrays_per_s": rays * world / elapsed / 1e6 if world == 1 else None,
             "rays_per_sample": rays / (W * H * S * args.steps),
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, S) if args.bvh == "reference" else None,
+                         "algorithmic_bytes_per_launch": rays * bytes_per_ray / launches,
                          "bytes_per_ray": bytes_per_ray, "entries_per_ray": work["entries"] / max(1, wst.rays),
                          "visits_per_ray": {k: round(work[k] / max(1, wst.rays), 4) for k in ROW_BYTES},
                          "ms_extend_per_step": ms_extend / args.steps, "ms_shade_per_step": ms_shade / args.steps,
