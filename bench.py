@@ -4,7 +4,7 @@ fits one GPU).
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one wavefront batch: `--spp-per-step` samples of every pixel (generate, then up to 50 bounces of
+A step is one wavefront batch: `--spp-per-step` samples of every pixel (default 256: 164 M path slots, 38 GB) (generate, then up to 50 bounces of
 extend + shade, then accumulate) rendered by every rank into its device-resident accumulation buffer; scene
 tables, path state and image never leave HBM inside the timed region. With N > 1 (one process per GPU,
 torch.distributed over RCCL) every rank renders its own sample range of every pixel (weak scaling: per-GPU
@@ -100,10 +100,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="final", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--spp-per-step", type=int, default=256)
     ap.add_argument("--bvh", default="reference", choices=["reference", "widest"],
                     help="BVHNode split axis: the reference's random axis (src/bvh.rs:24) or the widest spread of box minima")
-    ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the CPU baseline run (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the CPU baseline run (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=8, help="the reference's own thread count (src/main.rs:189)")
     args = ap.parse_args()
 

@@ -178,8 +178,17 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
     uint32_t max_active = (n + total_waves - 1u) / total_waves;
     max_active = max_active < 8u ? 8u : (max_active > 64u ? 64u : max_active);
     const uint32_t refill_at = REFILL_LANES < max_active ? REFILL_LANES : max_active;
-    const uint32_t chunk = n / total_waves >= RAY_MIN_CHUNKS * RAY_CHUNK ? RAY_CHUNK : 0u;
-    uint32_t c_next = 0u, c_end = 0u;
+    // Where the wave's rays come from. Large pools: the shared cursor, RAY_CHUNK rays per atomic (dynamic balance).
+    // Small pools: a fixed share per wave and no atomics at all; same-address atomics cost about 12 ns each however
+    // few rays there are, which would dominate the late bounces.
+    const bool dynamic = n / total_waves >= RAY_MIN_CHUNKS * RAY_CHUNK;
+    uint32_t c_next = 0u, c_end = 0u;  // the wave's reserved range (wave-uniform)
+    if (!dynamic) {
+        const uint32_t wave_id = blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
+        const uint32_t share = (n + total_waves - 1u) / total_waves;
+        c_next = wave_id * share < n ? wave_id * share : n;
+        c_end = c_next + share < n ? c_next + share : n;
+    }
     Walker<COUNT> w;
     w.done = true;
     typename IO::Ray ray;
@@ -200,26 +209,29 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
             }
             if (!exhausted && room > 0u) {
                 const uint32_t my_rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
-                // rays come from the wave's reserved range [c_next, c_end); when it runs short, one atomic
-                // reserves the missing rays plus (with many rays in the pool) a whole chunk for later refills
+                // rays come from the wave's reserved range [c_next, c_end); when it runs short and the pool is
+                // dynamic, one atomic reserves the missing rays plus a whole chunk for later refills
                 const uint32_t avail = c_end - c_next;
-                uint32_t base = 0u;
-                if (avail < room) {
-                    const uint32_t want = room - avail > chunk ? room - avail : chunk;
+                uint32_t take = room, base = 0u;
+                const bool more = dynamic && avail < room;
+                if (more) {
+                    const uint32_t want = room - avail > RAY_CHUNK ? room - avail : RAY_CHUNK;
                     if (lane == 0u) base = atomicAdd(cursor, want);
                     base = __shfl(base, 0, 64);
                     c_end = base + want;
+                } else if (avail < room) {
+                    take = avail;
                 }
                 const uint32_t mine = my_rank < avail ? c_next + my_rank : base + (my_rank - avail);
-                if (!busy && my_rank < room && mine < n) {
+                if (!busy && my_rank < take && mine < n) {
                     index = mine;
                     if (io.fetch(index, ray)) {
                         w.init(S, ray.o, ray.d, ray.tm, ray.tmin, ray.tmax);
                         busy = true;
                     }
                 }
-                c_next = avail < room ? base + (room - avail) : c_next + room;
-                exhausted = c_next >= n;
+                c_next = more ? base + (room - avail) : c_next + take;
+                exhausted = dynamic ? c_next >= n : c_next >= c_end;
             }
         }
         if (__ballot(busy) == 0ull) {
