@@ -114,9 +114,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no fallback)")
+    # RT_BENCH_REHEARSAL=1: several ranks share the GPUs that exist and talk over gloo, to exercise the N > 1
+    # code path on a box with fewer GPUs than ranks; never a measurement
+    rehearsal = os.environ.get("RT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
     L = lib.get()
@@ -151,11 +159,16 @@ def main():
         ms_extend += st.ms_extend
         ms_shade += st.ms_shade
         rays += st.rays
-    allreduce_accum(accum)
+    if rehearsal and world > 1:
+        host = accum.cpu()
+        allreduce_accum(host)
+        accum.copy_(host)
+    else:
+        allreduce_accum(accum)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -174,7 +187,7 @@ def main():
         out = {
             "metric": "path samples/s", "value": samples_total / elapsed, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, not a measurement)",
             "config": {"workload": wl["name"], "width": W, "height": H, "spp_per_step_per_gpu": S, "max_depth": 50, "bvh": args.bvh,
                        "sharding": "sample ranges per rank, one RCCL all-reduce of the f32 accumulation buffer"},
             "mrays_per_s": rays * world / elapsed / 1e6 if world == 1 else None,
