@@ -420,18 +420,35 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
     uint32_t o_next = 0u, o_end = 0u, survivors = 0u;
     // every lane of a wave runs the same number of iterations so that the ballot below sees whole waves
     const uint32_t n_round = (n + 63u) & ~63u;
+    // The record and hit of the next round are requested before the current round is shaded, so that their trip to
+    // HBM overlaps the arithmetic (two waves per SIMD cannot hide it otherwise).
+    V3 o_n = v3(0.0, 0.0, 0.0), d_n = o_n, T_n = o_n;
+    double tm_n = 0.0;
+    uint32_t slot_n = DEAD_SLOT;
+    uint4 h_n = make_uint4(0u, 0u, RT_MISS, 0u);
+    {
+        const uint32_t i0 = blockIdx.x * SHADE_BLOCK + threadIdx.x;
+        if (i0 < n) {
+            load_ray64(recs + i0, o_n, d_n, tm_n, slot_n);
+            load_throughput(recs + i0, T_n);
+            h_n = *reinterpret_cast<const uint4*>(P.hit + i0);
+        }
+    }
     for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_round; i += stride) {
         bool alive = false;
-        V3 no = v3(0.0, 0.0, 0.0), nd = no, T = no;
-        double tm = 0.0;
-        uint32_t slot = DEAD_SLOT;
-        V3 o = no, d = no;
-        if (i < n) {
-            load_ray64(recs + i, o, d, tm, slot);
-            load_throughput(recs + i, T);
+        V3 no = v3(0.0, 0.0, 0.0), nd = no;
+        const V3 o = o_n, d = d_n;
+        V3 T = T_n;
+        const double tm = tm_n;
+        const uint32_t slot = slot_n;
+        const uint4 h = h_n;
+        slot_n = DEAD_SLOT;
+        if (i + stride < n) {
+            load_ray64(recs + i + stride, o_n, d_n, tm_n, slot_n);
+            load_throughput(recs + i + stride, T_n);
+            h_n = *reinterpret_cast<const uint4*>(P.hit + i + stride);
         }
         if (slot != DEAD_SLOT) {
-            const uint4 h = *reinterpret_cast<const uint4*>(P.hit + i);
             Cand best;
             best.t = __hiloint2double((int)h.y, (int)h.x); best.ref = h.z; best.aux = h.w;
             if (best.ref == RT_MISS) {
