@@ -151,3 +151,31 @@ def test_full_resolution_properties(gpu, orc, sid):
     m_gpu, m_orc = both.mean() / 4, small.mean() / 16
     assert abs(m_gpu - m_orc) <= 0.12 * m_orc + 1e-3, (m_gpu, m_orc)
     ds.close(); hs.close(); orc.api.scene_free(osc)
+
+
+def test_whole_render_against_the_reference_picture(gpu):
+    # The GPU path against the one output of the Rust binary the reference holds: img/kaleidoscope.png, scene 11 at
+    # 800x800 (decoded pixels in tests/golden/kaleidoscope_reference_800.npz). At 64 spp the render must be that
+    # picture up to Monte-Carlo noise: RMSE below 1 level after 4x4 averaging, mean colour within 0.3 levels, and
+    # visibly worse when shifted by one row or column (the row convention of src/main.rs:206-208).
+    import os
+    from conftest import GOLDEN
+    ref = np.load(os.path.join(GOLDEN, "kaleidoscope_reference_800.npz"))["rgb"].astype(np.float64)
+    hs = lib.HostScene.build(11)
+    ds = lib.DeviceScene(hs)
+    su = gpu.host.scene_setup(11)
+    cam = gpu.host.camera(su)
+    spp = 64
+    acc, _ = ds.render(cam, lib.make_params(800, 800, 0, spp, list(su.background)))
+    img = lib.resolve_u8(acc, spp).astype(np.float64)
+    down = lambda a: a.reshape(200, 4, 200, 4, 3).mean((1, 3))
+    rmse = lambda a, b: float(np.sqrt(((a - b) ** 2).mean()))
+    assert rmse(down(img), down(ref)) < 1.0
+    assert np.abs((img - ref).reshape(-1, 3).mean(0)).max() < 0.3
+    here = rmse(img[8:-8, 8:-8], ref[8:-8, 8:-8])
+    assert here < 3.0
+    for axis in (0, 1):
+        for shift in (-1, 1):
+            assert rmse(np.roll(img, shift, axis=axis)[8:-8, 8:-8], ref[8:-8, 8:-8]) > here + 0.5
+    ds.close()
+    hs.close()

@@ -5,8 +5,10 @@ hit record. The reference itself holds no vectors for this path (its tests cover
 operators only), so these pin the oracle against its own regressions and give the GPU
 tests a fixed ray set; they are not outputs of the Rust binary.
 
-Also records loose statistics of the reference's example render img/kaleidoscope.png
-(README.md:11) when /root/reference is present."""
+Also converts the reference's example render img/kaleidoscope.png (README.md:11, the output of its scene 11 at
+800x800) into tests/golden/kaleidoscope_reference_800.npz (the decoded pixels, uint8 [800, 800, 3]) when
+/root/reference is present: the one output of the Rust binary the reference holds, against which whole renders of
+the oracle and of the GPU path are compared."""
 import json
 import os
 import sys
@@ -60,6 +62,12 @@ def main():
         meta["kaleidoscope_png"] = {"shape": list(img.shape), "mean_rgb": [float(x) for x in img.reshape(-1, 3).mean(0)],
                                     "min": float(img.min()), "max": float(img.max()),
                                     "corner_rgb": [int(x) for x in img[0, 0]], "centre_rgb": [int(x) for x in img[400, 400]]}
+        np.savez_compressed(os.path.join(OUT, "kaleidoscope_reference_800.npz"), rgb=img.astype(np.uint8))
+    elif os.path.exists(os.path.join(OUT, "meta.json")):  # keep what an earlier run recorded
+        with open(os.path.join(OUT, "meta.json")) as f:
+            old = json.load(f)
+        if "kaleidoscope_png" in old:
+            meta["kaleidoscope_png"] = old["kaleidoscope_png"]
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
 
