@@ -179,3 +179,30 @@ def test_whole_render_against_the_reference_picture(gpu):
             assert rmse(np.roll(img, shift, axis=axis)[8:-8, 8:-8], ref[8:-8, 8:-8]) > here + 0.5
     ds.close()
     hs.close()
+
+
+def test_large_batch_equals_small_batches_and_converges(gpu):
+    # The final scene at full size: one 128-spp batch (82 M path slots: the dynamic ray pool, chunked reservations and
+    # padding records all in play) against the same samples in 16-spp batches (the small-pool code paths in the late
+    # bounces), which must agree to f32 summation order; and two disjoint sample sets must agree within the noise
+    # their own spread predicts.
+    from raytracer_amd import assets
+    hs = lib.HostScene.build(9, image=assets.earthmap())
+    ds = lib.DeviceScene(hs)
+    su = gpu.host.scene_setup(9)
+    cam = gpu.host.camera(su)
+    W = H = 800
+    bg = list(su.background)
+    big, sb = ds.render(cam, lib.make_params(W, H, 0, 128, bg, samples_per_batch=128))
+    small, ss = ds.render(cam, lib.make_params(W, H, 0, 128, bg, samples_per_batch=16))
+    assert sb.rays == ss.rays and sb.batches == 1 and ss.batches == 8
+    assert np.allclose(big, small, rtol=1e-5, atol=1e-4)
+    other, _ = ds.render(cam, lib.make_params(W, H, 128, 256, bg, samples_per_batch=128))
+    a, b = big / 128.0, other / 128.0
+    # per-pixel difference of two 128-sample means against the image-wide level: converging, not biased
+    assert abs(a.mean() - b.mean()) < 0.01 * a.mean()
+    blocks = lambda x: x.reshape(100, 8, 100, 8, 3).mean((1, 3))
+    rel = np.abs(blocks(a) - blocks(b)).mean() / blocks(a).mean()
+    assert rel < 0.12, rel
+    ds.close()
+    hs.close()
