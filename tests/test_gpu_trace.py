@@ -101,6 +101,25 @@ def test_widest_axis_tree_parity_and_work(gpu, orc, sid):
     orc.api.scene_free(osc)
 
 
+@pytest.mark.parametrize("sid", [9, 12])
+def test_large_ray_pool(gpu, sid):
+    # 2.6 M rays (the golden set repeated in a shuffled order): the pool is large enough for the waves to reserve
+    # rays in chunks through the shared cursor instead of taking fixed shares; every copy must get the golden hit
+    g = load_golden(sid)
+    reps = 640
+    rng = np.random.default_rng(sid)
+    order = rng.permutation(len(g["rays"]) * reps) % len(g["rays"])
+    hs = lib.HostScene.build(sid, seed=SEED, **scene_kwargs(sid))
+    ds = lib.DeviceScene(hs)
+    hits, _ = ds.trace(g["rays"][order], seed=SEED)
+    want = g["hits"][order]
+    assert np.array_equal(hits["prim_id"], want["prim_id"]) and np.array_equal(hits["sub"], want["sub"])
+    hit = want["prim_id"] != abi.RT_MISS
+    assert ulp_diff(want["t"][hit], hits["t"][hit]).max(initial=0) <= T_ULP
+    ds.close()
+    hs.close()
+
+
 def random_scene_pair(rng, rtlib, orc, n_obj):
     """The same random ad-hoc scene in the product builder and the oracle builder."""
     # identical call sequence and scene-stream seed (it picks the BVH split axes) on both
