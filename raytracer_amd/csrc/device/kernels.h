@@ -337,12 +337,9 @@ __global__ void __launch_bounds__(BLOCK) k_generate(RenderConst C, PathState P) 
 }
 
 // ---- extend ------------------------------------------------------------------------------
-struct RayRecRef {  // where a query's world ray lives (re-read when a wrapper is left)
-    const RayRec* r;
-    RT_D void load(V3& o, V3& d) const {
-        double tm; uint32_t slot;
-        load_ray64(r, o, d, tm, slot);
-    }
+struct RayRecRef {  // the query's world ray, kept in registers: needed again whenever a wrapper is left
+    V3 wo, wd;
+    RT_D void load(V3& o, V3& d) const { o = wo; d = wd; }
 };
 struct ExtendIO {
     const RayRec* recs;
@@ -359,9 +356,9 @@ struct ExtendIO {
     };
     RT_D uint32_t n() const { return count; }
     RT_D bool fetch(uint32_t i, Ray& r) const {  // false: a padding record, no ray
-        r.rs.r = recs + i;
         uint32_t slot;
         load_ray64(recs + i, r.o, r.d, r.tm, slot);
+        r.rs.wo = r.o; r.rs.wd = r.d;
         r.key.seed = seed; r.key.pixel = slot % npix; r.key.sample = sample0 + slot / npix; r.key.bounce = bounce;
         return slot != DEAD_SLOT;
     }

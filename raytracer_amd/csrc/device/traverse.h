@@ -424,24 +424,46 @@ struct Walker {
             }
             case RT_N_XF_ENTER: {
                 RT_DIAG_LEAF(RT_N_XF_ENTER)
-                const auto x = S.xforms + idx;
-                V3 o = g.o, d = g.d;
-                xf_apply(x, o, d);
-                if (x->kind == 0u) g.set_origin(o);
-                else g.set_xz(o.x, o.z, d.x, d.z);
-                cur_xf = idx + 1u;
+                // a run of wrappers (Translate around RotateY, src/main.rs:690-696) is entered in one step
+                uint32_t xi = idx;
+                for (;;) {
+                    const auto x = S.xforms + xi;
+                    V3 o = g.o, d = g.d;
+                    xf_apply(x, o, d);
+                    if (x->kind == 0u) g.set_origin(o);
+                    else g.set_xz(o.x, o.z, d.x, d.z);
+                    cur_xf = xi + 1u;
+                    const uint32_t next = S.nodes[i + 1u].meta;
+                    if ((next & 15u) != RT_N_XF_ENTER) break;
+                    if (COUNT) { work->entries++; work->prim[RT_N_XF_ENTER]++; }
+                    xi = next >> 4;
+                    ++i;
+                }
                 break;
             }
             case RT_N_XF_EXIT: {
                 RT_DIAG_LEAF(RT_N_XF_EXIT)
-                // back in the parent's space: its ray is the stored world ray pushed through the parent's chain
-                const auto x = S.xforms + idx;
-                const uint32_t depth = x->depth;
-                cur_xf = depth > 1u ? x->anc[depth - 2u] + 1u : 0u;
+                // back in the space of the first enclosing wrapper that is not left here as well (or the world):
+                // its ray is the world ray pushed through that wrapper's chain
+                uint32_t xi = idx;
+                bool rotated = false;
+                for (;;) {
+                    const auto x = S.xforms + xi;
+                    rotated = rotated || x->kind != 0u;
+                    const uint32_t depth = x->depth;
+                    cur_xf = depth > 1u ? x->anc[depth - 2u] + 1u : 0u;
+                    if (i + 1u >= end) break;
+                    const uint32_t next = S.nodes[i + 1u].meta;
+                    if ((next & 15u) != RT_N_XF_EXIT) break;
+                    if (COUNT) { work->entries++; work->prim[RT_N_XF_EXIT]++; }
+                    xi = next >> 4;
+                    ++i;
+                }
                 V3 o, d;
                 ray_at(S, rs, cur_xf, o, d);
-                if (x->kind == 0u) g.set_origin(o);   // leaving a Translate: the direction was never changed
-                else g.set_xz(o.x, o.z, d.x, d.z);    // leaving a RotateY: y components were never changed
+                if (!rotated) g.set_origin(o);        // only Translates were left: the direction was never changed
+                else g.set_xz(o.x, o.z, d.x, d.z);    // a RotateY was left: y components were never changed ...
+                if (rotated) g.set_origin(o);         // ... but a Translate left with it may have moved the origin's y
                 break;
             }
             default: {  // RT_N_MEDIUM, ConstantMedium::hit src/constant_medium.rs:34-89 (mode is 0 here)
