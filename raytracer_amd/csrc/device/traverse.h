@@ -348,36 +348,44 @@ struct Walker {
     template <class SC>
     RT_D void box_run(const SC& S, const RayKey& key, Work* work) {
         for (;;) {
-            if (i >= end) {
-                if (mode == 0u) { done = true; return; }
-                // end of a boundary query; `end` is the medium's link
-                if (mode == 1u && best.ref != RT_MISS) {
-                    t_enter = best.t;
-                    tmin = best.t + 0.0001;  // src/constant_medium.rs:45
-                    best.t = D_INF;
-                    best.ref = RT_MISS;
-                    mode = 2u;
-                    i = med_begin;
-                    continue;
+            // the hot loop: nothing but the entry index changes in it
+            {
+                uint32_t j = i;
+                const uint32_t stop = end;
+                const double lo = tmin, hi = best.t;
+                bool leaf_found = false;
+                while (j < stop) {
+                    load_node(S.nodes + j, na, nb);
+#ifdef RT_DIAG_WAVE
+                    if (COUNT && (nb.z & 15u) == RT_N_INNER && diag_first_lane()) { work->entries++; work->prim[RT_N_INNER]++; }
+#else
+                    if (COUNT) { work->entries++; work->prim[nb.z & 15u]++; }
+#endif
+                    if ((nb.z & 15u) != RT_N_INNER) { leaf_found = true; break; }
+                    j = box_hit(na, nb, g, lo, hi) ? j + 1u : nb.w;
                 }
-                const bool inside = best.ref != RT_MISS;  // mode 2 and the second query hit
-                const double t2 = best.t;
-                best.t = out_t; best.ref = out_ref; best.aux = out_aux;
-                tmin = tmin0;
-                i = end;
-                end = S.n_nodes;
-                mode = 0u;
-                if (inside) resolve_medium(S, key, med_meta, t_enter, t2);
+                i = j;
+                if (leaf_found) return;
+            }
+            // i >= end: the end of the world, or of a boundary query (`end` is then the medium's link)
+            if (mode == 0u) { done = true; return; }
+            if (mode == 1u && best.ref != RT_MISS) {
+                t_enter = best.t;
+                tmin = best.t + 0.0001;  // src/constant_medium.rs:45
+                best.t = D_INF;
+                best.ref = RT_MISS;
+                mode = 2u;
+                i = med_begin;
                 continue;
             }
-            load_node(S.nodes + i, na, nb);
-#ifdef RT_DIAG_WAVE
-            if (COUNT && (nb.z & 15u) == RT_N_INNER && diag_first_lane()) { work->entries++; work->prim[RT_N_INNER]++; }
-#else
-            if (COUNT) { work->entries++; work->prim[nb.z & 15u]++; }
-#endif
-            if ((nb.z & 15u) != RT_N_INNER) return;
-            i = box_hit(na, nb, g, tmin, best.t) ? i + 1u : nb.w;
+            const bool inside = best.ref != RT_MISS;  // mode 2 and the second query hit
+            const double t2 = best.t;
+            best.t = out_t; best.ref = out_ref; best.aux = out_aux;
+            tmin = tmin0;
+            i = end;
+            end = S.n_nodes;
+            mode = 0u;
+            if (inside) resolve_medium(S, key, med_meta, t_enter, t2);
         }
     }
 
