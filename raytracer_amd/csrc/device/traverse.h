@@ -167,8 +167,12 @@ RT_D bool box_hit(const uint4 na, const uint4 nb, const Seg& g, double tmin, dou
     const double t1y = fma((double)(sy ? loy : hiy), g.invd.y, g.noi.y);
     const double t0z = fma((double)(sz ? hiz : loz), g.invd.z, g.noi.z);
     const double t1z = fma((double)(sz ? loz : hiz), g.invd.z, g.noi.z);
-    const double lo = fmax(fmax(fmax(t0x, t0y), t0z), tmin);
-    const double hi = fmin(fmin(fmin(t1x, t1y), t1z), tmax);
+    // The last max / min take the interval bounds, values the compiler cannot prove free of signalling NaNs; written
+    // as the bare instructions they cost one operation each instead of two (a quieting max(x, x) first). No value
+    // here is ever a signalling NaN, for which alone the two forms differ.
+    double lo = fmax(fmax(t0x, t0y), t0z), hi = fmin(fmin(t1x, t1y), t1z);
+    asm("v_max_f64 %0, %1, %2" : "=v"(lo) : "v"(lo), "v"(tmin));
+    asm("v_min_f64 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(tmax));
     return !(hi <= lo) || (tmin != tmin) || (tmax != tmax);
 }
 
