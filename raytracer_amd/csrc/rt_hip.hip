@@ -122,6 +122,7 @@ int validate(const RtSceneDesc* d) {
         }
         if (kind == RT_N_MEDIUM) {
             if (medium_end) return bad("medium inside a medium boundary");
+            if (n.link == i + 1u) return bad("medium without a boundary");  // the walk looks at the entry after it
             medium_end = n.link;
         }
         if (kind == RT_N_XF_ENTER) {

@@ -98,6 +98,17 @@ def test_scene_create_rejects_malformed_descriptions(rtlib):
     rc = rtlib.lib.rt_scene_create(None, C.byref(C.c_void_p()))
     assert rc == -1
     hs.close()
+    # a medium entry must be followed by its boundary
+    hs = lib.HostScene.build(8)
+    good = hs.desc
+    nodes = (abi.RtNode * good.n_nodes)()
+    C.memmove(nodes, good.nodes, C.sizeof(nodes))
+    d = clone(); d.nodes = nodes
+    med = next(i for i in range(good.n_nodes) if (nodes[i].meta & 15) == 8)
+    nodes[med].link = med + 1
+    rc, msg = create(d)
+    assert rc == -1 and ("boundary" in msg or "link" in msg or "wrapper" in msg)
+    hs.close()
 
 
 def test_null_arguments_return_codes(rtlib):
