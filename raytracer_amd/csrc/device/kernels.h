@@ -136,6 +136,34 @@ RT_D SceneT<true> stage_scene(const DevScene& S, const LdsPlan& plan) {
 #define RT_SHADE_WAVES 2
 #endif
 
+// The same for a scene that does not fit as a whole: the tables the plan names are copied into LDS, the others
+// stay where they are, and the kernel reaches both through generic pointers (flat loads).
+template <class T>
+RT_D const T* stage_table_generic(const T* src, uint32_t bytes, uint32_t& off) {
+    if (bytes == 0u) return src;
+    return (const T*)stage_table(src, bytes, off);
+}
+RT_D DevScene stage_scene_partial(const DevScene& S, const LdsPlan& plan) {
+    DevScene L = S;
+    uint32_t off = 0u;
+    L.nodes = stage_table_generic(S.nodes, plan.nodes, off);
+    L.boxes = stage_table_generic(S.boxes, plan.boxes, off);
+    L.spheres = stage_table_generic(S.spheres, plan.spheres, off);
+    L.msphere = stage_table_generic(S.msphere, plan.msphere, off);
+    L.rects = stage_table_generic(S.rects, plan.rects, off);
+    L.triangles = stage_table_generic(S.triangles, plan.triangles, off);
+    L.xforms = stage_table_generic(S.xforms, plan.xforms, off);
+    L.media = stage_table_generic(S.media, plan.media, off);
+    L.materials = stage_table_generic(S.materials, plan.materials, off);
+    L.textures = stage_table_generic(S.textures, plan.textures, off);
+    L.perlins = stage_table_generic(S.perlins, plan.perlins, off);
+    __syncthreads();
+    return L;
+}
+RT_D bool plan_is_empty(const LdsPlan& p) {
+    return (p.nodes | p.boxes | p.spheres | p.msphere | p.rects | p.triangles | p.xforms | p.media | p.materials | p.textures | p.perlins) == 0u;
+}
+
 // ---- persistent closest-hit loop ----------------------------------------------------------
 // Rays of one launch form a pool; every wave pulls rays from it through one shared cursor and keeps its
 // lanes busy: a lane whose query has finished stores its result and, as soon as enough lanes of the wave are
@@ -316,8 +344,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK, 2) k_trace(DevScene S0, LdsPlan p
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
         extend_pool<COUNT>(S, io, cursor, work_out);
-    } else {
+    } else if (plan_is_empty(plan)) {
         extend_pool<COUNT>(S0, io, cursor, work_out);
+    } else {
+        const DevScene S = stage_scene_partial(S0, plan);
+        extend_pool<COUNT>(S, io, cursor, work_out);
     }
 }
 
@@ -383,8 +414,11 @@ __global__ void __launch_bounds__(LDS ? EXT_BLOCK : EXT_BLOCK_GLOBAL, LDS ? RT_E
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
         extend_pool<COUNT>(S, io, counts + 2, work_out);
-    } else {
+    } else if (plan_is_empty(plan)) {
         extend_pool<COUNT>(S0, io, counts + 2, work_out);
+    } else {
+        const DevScene S = stage_scene_partial(S0, plan);
+        extend_pool<COUNT>(S, io, counts + 2, work_out);
     }
 }
 
@@ -504,8 +538,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK, RT_SHADE_WAVES) k_shade(DevScene 
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
         shade_all(S, C, P, counts, cur, bounce, ray_total);
-    } else {
+    } else if (plan_is_empty(plan)) {
         shade_all(S0, C, P, counts, cur, bounce, ray_total);
+    } else {
+        const DevScene S = stage_scene_partial(S0, plan);
+        shade_all(S, C, P, counts, cur, bounce, ray_total);
     }
 }
 

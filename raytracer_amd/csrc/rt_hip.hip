@@ -271,15 +271,15 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
                     if (work) hipLaunchKernelGGL((rtd::k_extend<true, true>), eg, eb, s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
                     else hipLaunchKernelGGL((rtd::k_extend<false, true>), eg, eb, s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
                 } else {
-                    if (work) hipLaunchKernelGGL((rtd::k_extend<true, false>), eg, eb, 0, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
-                    else hipLaunchKernelGGL((rtd::k_extend<false, false>), eg, eb, 0, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
+                    if (work) hipLaunchKernelGGL((rtd::k_extend<true, false>), eg, eb, s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
+                    else hipLaunchKernelGGL((rtd::k_extend<false, false>), eg, eb, s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
                 }
             }
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
             {
                 const dim3 sg(std::min(s->grid_shade, (C.n_slots + rtd::SHADE_BLOCK - 1) / rtd::SHADE_BLOCK)), sb(rtd::SHADE_BLOCK);
                 if (s->shade_lds) hipLaunchKernelGGL(rtd::k_shade<true>, sg, sb, s->lds_bytes_shade, stream, s->S, s->plan_shade, C, w.P, w.counts, cur, bounce, w.ray_total);
-                else hipLaunchKernelGGL(rtd::k_shade<false>, sg, sb, 0, stream, s->S, s->plan_shade, C, w.P, w.counts, cur, bounce, w.ray_total);
+                else hipLaunchKernelGGL(rtd::k_shade<false>, sg, sb, s->lds_bytes_shade, stream, s->S, s->plan_shade, C, w.P, w.counts, cur, bounce, w.ray_total);
             }
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
         }
@@ -364,7 +364,44 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
             }
             s->extend_lds = ext <= kBudget && d->n_nodes > 0;
             s->shade_lds = shd <= kBudget && d->n_nodes > 0;
+            // A scene that does not fit as a whole: the tables read most often go first, as many as fit
+            auto take = [&](uint32_t& field, uint64_t bytes, uint32_t& used) {
+                if (bytes && used + pad(bytes) <= kBudget) { field = (uint32_t)bytes; used += (uint32_t)pad(bytes); }
+            };
+            if (!s->extend_lds && d->n_nodes > 0 && pad(d->n_nodes * sizeof(RtNode)) <= kBudget) {  // not without the entries
+                uint32_t used = 0;
+                take(s->plan.nodes, d->n_nodes * sizeof(RtNode), used);
+                take(s->plan.xforms, d->n_xforms * sizeof(RtXform), used);
+                take(s->plan.media, d->n_media * sizeof(RtMedium), used);
+                take(s->plan.spheres, d->n_spheres * sizeof(RtSphere), used);
+                take(s->plan.msphere, d->n_msphere * sizeof(RtMovingSphere), used);
+                take(s->plan.rects, d->n_rects * sizeof(RtRect), used);
+                take(s->plan.boxes, d->n_boxes * sizeof(RtBox6), used);
+                take(s->plan.triangles, d->n_triangles * sizeof(RtTriangle), used);
+                s->lds_bytes = used;
+            }
+            if (!s->shade_lds && d->n_nodes > 0) {
+                uint32_t used = 0;
+                take(s->plan_shade.materials, d->n_materials * sizeof(RtMaterial), used);
+                take(s->plan_shade.textures, d->n_textures * sizeof(RtTexture), used);
+                take(s->plan_shade.perlins, d->n_perlins * sizeof(RtPerlin), used);
+                take(s->plan_shade.xforms, d->n_xforms * sizeof(RtXform), used);
+                take(s->plan_shade.media, d->n_media * sizeof(RtMedium), used);
+                take(s->plan_shade.spheres, d->n_spheres * sizeof(RtSphere), used);
+                take(s->plan_shade.msphere, d->n_msphere * sizeof(RtMovingSphere), used);
+                take(s->plan_shade.rects, d->n_rects * sizeof(RtRect), used);
+                take(s->plan_shade.boxes, d->n_boxes * sizeof(RtBox6), used);
+                take(s->plan_shade.triangles, d->n_triangles * sizeof(RtTriangle), used);
+                s->lds_bytes_shade = used;
+            }
             const int big = (int)kBudget;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -375,12 +412,12 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         }
         int per_cu = 0;
         hipError_t oe = s->extend_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, true>, rtd::EXT_BLOCK, s->lds_bytes)
-                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, false>, rtd::EXT_BLOCK_GLOBAL, 0);
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, false>, rtd::EXT_BLOCK_GLOBAL, s->lds_bytes);
         if (oe != hipSuccess || per_cu < 1) per_cu = 1;
         s->grid_extend = s->n_cus * (uint32_t)per_cu;
         int shade_per_cu = 0;
         oe = s->shade_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, rtd::k_shade<true>, rtd::SHADE_BLOCK, s->lds_bytes_shade)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, rtd::k_shade<false>, rtd::SHADE_BLOCK, 0);
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, rtd::k_shade<false>, rtd::SHADE_BLOCK, s->lds_bytes_shade);
         if (oe != hipSuccess || shade_per_cu < 1) shade_per_cu = 1;
 #ifndef RT_SHADE_GRID_MULT
 #define RT_SHADE_GRID_MULT 1
@@ -425,7 +462,7 @@ int rt_trace_closest_device(RtScene* s, const RtRay* rays_dev, uint64_t n, uint6
         hipLaunchKernelGGL((rtd::k_trace<false, false, true>), dim3(trace_grid(s, n)), dim3(rtd::TRACE_BLOCK), s->lds_bytes, (hipStream_t)stream, s->S, s->plan,
                            rays_dev, n, seed, out_dev, (RtHitRecord*)nullptr, s->ws.counts + 3, (unsigned long long*)nullptr);
     else
-        hipLaunchKernelGGL((rtd::k_trace<false, false, false>), dim3(trace_grid(s, n)), dim3(rtd::TRACE_BLOCK), 0, (hipStream_t)stream, s->S, s->plan,
+        hipLaunchKernelGGL((rtd::k_trace<false, false, false>), dim3(trace_grid(s, n)), dim3(rtd::TRACE_BLOCK), s->lds_bytes, (hipStream_t)stream, s->S, s->plan,
                            rays_dev, n, seed, out_dev, (RtHitRecord*)nullptr, s->ws.counts + 3, (unsigned long long*)nullptr);
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -474,7 +511,7 @@ int trace_host(RtScene* s, const RtRay* rays, uint64_t n, uint64_t seed, RtHit* 
         HIP_TRY(hipEventRecord(e0, nullptr));
         RtHit* oh = recs ? nullptr : (RtHit*)d_out;
         RtHitRecord* orc = recs ? (RtHitRecord*)d_out : nullptr;
-#define RT_LAUNCH_TRACE(R, W, L) hipLaunchKernelGGL((rtd::k_trace<R, W, L>), grid, block, (L) ? s->lds_bytes : 0u, nullptr, s->S, s->plan, d_rays, n, seed, oh, orc, cursor, d_work)
+#define RT_LAUNCH_TRACE(R, W, L) hipLaunchKernelGGL((rtd::k_trace<R, W, L>), grid, block, s->lds_bytes, nullptr, s->S, s->plan, d_rays, n, seed, oh, orc, cursor, d_work)
         const int variant = (recs ? 4 : 0) | (work ? 2 : 0) | (s->extend_lds ? 1 : 0);
         switch (variant) {
             case 0: RT_LAUNCH_TRACE(false, false, false); break;
