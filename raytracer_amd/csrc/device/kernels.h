@@ -76,10 +76,10 @@ struct RenderConst {
 
 constexpr int BLOCK = 256;
 #ifndef RT_EXT_BLOCK_GLOBAL
-#define RT_EXT_BLOCK_GLOBAL 1024
+#define RT_EXT_BLOCK_GLOBAL 768
 #endif
 #ifndef RT_EXTEND_WAVES_GLOBAL
-#define RT_EXTEND_WAVES_GLOBAL 4
+#define RT_EXTEND_WAVES_GLOBAL 3
 #endif
 constexpr int EXT_BLOCK_GLOBAL = RT_EXT_BLOCK_GLOBAL;  // extend when the tables stay in global memory
 constexpr int EXT_BLOCK = 768;    // extend: one 12-wave workgroup per CU sharing one LDS copy of the scene tables
