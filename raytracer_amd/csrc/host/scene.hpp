@@ -11,10 +11,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <limits>
+#include <future>
 #include <memory>
-#include <stdexcept>
 #include <unordered_map>
+#include <stdexcept>
 #include <vector>
 
 #include "../../../include/rt/abi.h"
@@ -579,44 +581,92 @@ inline int widest_axis(const std::vector<HitPtr>& objects, size_t start, size_t 
     return best;
 }
 
-inline std::shared_ptr<BVHNode> new_from_list(std::vector<HitPtr>& objects, size_t start, size_t end, double time0,
-                                              double time1) {  // src/bvh.rs:17-91
-    int axis = random_int(0, 2);  // drawn for every node, also span 1 and 2 (:24)
-    const size_t span = end - start;
-    if (g_bvh_widest_axis && span > 1) axis = widest_axis(objects, start, end);
-    auto node = std::make_shared<BVHNode>();
-    if (span == 1) {
-        node->left = node->right = objects[start];
-    } else if (span == 2) {
-        if (box_key(objects[start + 1], axis) < box_key(objects[start], axis)) {  // Ordering::Greater (:54-60)
-            node->left = objects[start + 1];
-            node->right = objects[start];
-        } else {
-            node->left = objects[start];
-            node->right = objects[start + 1];
-        }
-    } else {
-        // slice::sort_by(comparator) is a stable sort (:70). Keys are extracted once per level; a stable
-        // sort by key gives the same permutation as the comparator-based one.
-        std::vector<std::pair<double, HitPtr>> keyed;
-        keyed.reserve(span);
-        for (size_t i = start; i < end; ++i) keyed.emplace_back(box_key(objects[i], axis), std::move(objects[i]));
-        std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-        for (size_t i = 0; i < span; ++i) objects[start + i] = std::move(keyed[i].second);
-        const size_t mid = start + span / 2;
-        node->left = new_from_list(objects, start, mid, time0, time1);
-        node->right = new_from_list(objects, mid, end, time0, time1);
+// BVHNode::new draws one random_int per node, in depth-first order (src/bvh.rs:24). The scene stream is
+// counter-based, so the draw of every node is known from its position alone and large subtrees can be built by
+// separate threads while the tree stays the one a sequential build gives.
+inline uint64_t rng_position(const rt::Rng& r) { return (uint64_t)r.k | ((uint64_t)r.k_hi << 32); }
+inline void rng_seek(rt::Rng& r, uint64_t draw) {
+    r.k = (uint32_t)draw;
+    r.k_hi = (uint32_t)(draw >> 32);
+    if (r.k & 1u) {  // the second draw of a block: its first half was consumed, the second waits in `spare`
+        const rt::Philox4 o = rt::philox4x32_10(r.a, r.b, r.c, (r.k >> 1) | (r.k_hi << 31), r.k0, r.k1);
+        r.spare = ((uint64_t)o.v[3] << 32) | o.v[2];
     }
-    AABB bl, br;
-    if (!node->left->bounding_box(time0, time1, bl) || !node->right->bounding_box(time0, time1, br))
-        throw std::runtime_error("object without a bounding box in BVHNode::new");  // :83-87
-    node->_box = surrounding_box(bl, br);
-    return node;
 }
+
+struct BvhBuild {
+    std::vector<HitPtr>& objects;
+    double time0, time1;
+    rt::Rng base;                                  // the scene stream (position irrelevant)
+    bool widest;
+    std::unordered_map<size_t, uint64_t> draws;    // nodes (= draws) of a subtree over n objects
+
+    uint64_t count_draws(size_t n) {
+        if (n <= 2) return 1;
+        auto it = draws.find(n);
+        if (it != draws.end()) return it->second;
+        const uint64_t d = 1 + count_draws(n / 2) + count_draws(n - n / 2);
+        draws.emplace(n, d);
+        return d;
+    }
+    uint64_t draws_of(size_t n) const { return n <= 2 ? 1 : draws.at(n); }
+
+    // src/bvh.rs:17-91; `draw` = index of this node's random_int in the scene stream
+    std::shared_ptr<BVHNode> build(size_t start, size_t end, uint64_t draw, int fork_levels) const {
+        rt::Rng r = base;
+        rng_seek(r, draw);
+        int axis = (int)r.uniform(0.0, 3.0);  // random_int(0, 2), drawn for every node, also span 1 and 2 (:24)
+        const size_t span = end - start;
+        if (widest && span > 1) axis = widest_axis(objects, start, end);
+        auto node = std::make_shared<BVHNode>();
+        if (span == 1) {
+            node->left = node->right = objects[start];
+        } else if (span == 2) {
+            if (box_key(objects[start + 1], axis) < box_key(objects[start], axis)) {  // Ordering::Greater (:54-60)
+                node->left = objects[start + 1];
+                node->right = objects[start];
+            } else {
+                node->left = objects[start];
+                node->right = objects[start + 1];
+            }
+        } else {
+            // slice::sort_by(comparator) is a stable sort (:70). Keys are extracted once per level; a stable
+            // sort by key gives the same permutation as the comparator-based one.
+            std::vector<std::pair<double, HitPtr>> keyed;
+            keyed.reserve(span);
+            for (size_t i = start; i < end; ++i) keyed.emplace_back(box_key(objects[i], axis), std::move(objects[i]));
+            std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+            for (size_t i = 0; i < span; ++i) objects[start + i] = std::move(keyed[i].second);
+            keyed = {};
+            const size_t mid = start + span / 2;
+            const uint64_t d_left = draw + 1, d_right = d_left + draws_of(mid - start);
+            if (fork_levels > 0 && span >= 65536) {
+                auto left = std::async(std::launch::async, [&]() { return build(start, mid, d_left, fork_levels - 1); });
+                node->right = build(mid, end, d_right, fork_levels - 1);
+                node->left = left.get();
+            } else {
+                node->left = build(start, mid, d_left, 0);
+                node->right = build(mid, end, d_right, 0);
+            }
+        }
+        AABB bl, br;
+        if (!node->left->bounding_box(time0, time1, bl) || !node->right->bounding_box(time0, time1, br))
+            throw std::runtime_error("object without a bounding box in BVHNode::new");  // :83-87
+        node->_box = surrounding_box(bl, br);
+        return node;
+    }
+};
 
 inline std::shared_ptr<BVHNode> BVHNode::create(HittableList& list, double time0, double time1) {
     if (list.objects.empty()) throw std::invalid_argument("BVHNode::new on an empty list");
-    return new_from_list(list.objects, 0, list.objects.size(), time0, time1);
+    BvhBuild b{list.objects, time0, time1, ctx().rng, g_bvh_widest_axis, {}};
+    const uint64_t first = rng_position(ctx().rng);
+    const uint64_t total = b.count_draws(list.objects.size());
+    int fork_levels = 4;  // up to 16 subtrees at a time; RT_BVH_FORK_LEVELS=0 builds on the calling thread alone
+    if (const char* e = std::getenv("RT_BVH_FORK_LEVELS")) fork_levels = std::max(0, std::min(8, std::atoi(e)));
+    auto root = b.build(0, list.objects.size(), first, fork_levels);
+    rng_seek(ctx().rng, first + total);
+    return root;
 }
 
 // ---- camera (src/camera.rs:27-59) -------------------------------------------

@@ -101,6 +101,26 @@ def test_widest_axis_tree_parity_and_work(gpu, orc, sid):
     orc.api.scene_free(osc)
 
 
+def test_forked_host_bvh_build_is_the_oracles_tree(gpu, orc):
+    # 200 000 triangles: the product host builds the subtrees of the top levels on separate threads, the oracle builds
+    # sequentially; same hits and exactly the same traversal work means the same tree
+    kw = dict(n_triangles=200000)
+    hs = lib.HostScene.build(12, seed=SEED, **kw)
+    ds = lib.DeviceScene(hs)
+    osc = orc.api.scene_build(12, seed=SEED, **kw)
+    su = orc.api.scene_setup(12)
+    cam = orc.api.camera(su)
+    p = orc.make_params(128, 128, 0, 2, list(su.background), seed=SEED)
+    rays = orc.harvest(osc, cam, p, n_paths=20000, max_rays=1 << 15, max_bounce=3)
+    oh, _, ost = orc.trace(osc, rays, seed=SEED, mode=oracle.AABB_TIGHT)
+    gh, work = ds.trace_work(rays, seed=SEED)
+    compare_hits(oh, gh, "200k-triangle mesh")
+    assert work["inner"] == ost["box_tests"] and work["triangle"] == ost["triangle"] and work["box6"] == ost["box6"]
+    ds.close()
+    hs.close()
+    orc.api.scene_free(osc)
+
+
 @pytest.mark.parametrize("sid", [9, 12])
 def test_large_ray_pool(gpu, sid):
     # 2.6 M rays (the golden set repeated in a shuffled order): the pool is large enough for the waves to reserve

@@ -207,6 +207,32 @@ def test_widest_axis_flag_matches_the_oracle_tree(rtlib, orc):
         wide.close()
 
 
+def test_forked_bvh_build_gives_the_sequential_tree(rtlib, monkeypatch):
+    # subtrees over 65536 and more objects are built by separate threads; every node's split-axis draw is addressed by
+    # its position in the scene stream, so the tree must be the one a single thread builds
+    tables = []
+    for levels in ("0", "4"):
+        monkeypatch.setenv("RT_BVH_FORK_LEVELS", levels)
+        hs = lib.HostScene.build(12, seed=SEED, n_triangles=300000)
+        tables.append((hs.table("nodes").tobytes(), hs.table("triangles").tobytes()))
+        hs.close()
+    assert tables[0] == tables[1]
+    # and draws made after the build continue where a sequential build leaves the stream
+    def two_bvhs():
+        b = rtlib.host.builder(seed=11)
+        m = b.lambertian([0.5, 0.5, 0.5])
+        first = b.bvh(b.list([b.sphere([float(i), 0.0, 0.0], 0.3, m) for i in range(40)]))
+        second = b.bvh(b.list([b.sphere([0.0, float(i), 0.0], 0.3, m) for i in range(40)]))
+        hs = lib.HostScene(rtlib, b.finish(b.bvh(b.list([first, second]))))
+        out = hs.table("nodes").tobytes()
+        hs.close()
+        return out
+    monkeypatch.setenv("RT_BVH_FORK_LEVELS", "0")
+    a = two_bvhs()
+    monkeypatch.setenv("RT_BVH_FORK_LEVELS", "4")
+    assert a == two_bvhs()
+
+
 def test_mesh_scene_counts(rtlib):
     hs = lib.HostScene.build(12, n_triangles=5000)
     G = int(np.ceil(np.sqrt(5000 / 8.0)))
