@@ -5,7 +5,8 @@
 // (origin, direction, time, slot, throughput); every bounce is two launches over it:
 //   extend: closest hit of record i            -> hit[i]                        (src/color.rs:41)
 //   shade : rebuild the HitRecord, add emitted light, scatter; survivors are written, compacted
-//           with one ballot and one atomic per wave, into the other record array  (src/color.rs:50-62)
+//           with one ballot per wave into record ranges the wave reserves 256 at a time, into the
+//           other record array                                                   (src/color.rs:50-62)
 // so both kernels stream consecutive records instead of chasing an index queue, and a path costs one
 // record read per kernel. Radiance gathered by a path lives in per-slot columns (slot = local_sample *
 // n_pixels + pixel) that are touched only when light is added (miss or emitter) and summed per pixel by
@@ -33,11 +34,11 @@ struct PathState {
     double *lr, *lg, *lb;       // radiance gathered so far, per slot
 };
 
-// 16-byte loads/stores of a record (global_load_dwordx4 / global_store_dwordx4)
 // slot value of a padding record: the shade kernel reserves output records in chunks and pads what a wave did
 // not use; extend and shade skip such records
 constexpr uint32_t DEAD_SLOT = 0xFFFFFFFFu;
 
+// 16-byte loads/stores of a record (global_load_dwordx4 / global_store_dwordx4)
 RT_D void load_ray64(const RayRec* r, V3& o, V3& d, double& tm, uint32_t& slot) {
     const double2* p = reinterpret_cast<const double2*>(r);
     const double2 a = p[0], b = p[1], c = p[2];
@@ -165,10 +166,10 @@ RT_D bool plan_is_empty(const LdsPlan& p) {
 }
 
 // ---- persistent closest-hit loop ----------------------------------------------------------
-// Rays of one launch form a pool; every wave pulls rays from it through one shared cursor and keeps its
-// lanes busy: a lane whose query has finished stores its result and, as soon as enough lanes of the wave are
-// idle, the idle lanes pull new rays together (one atomic per refill) while the other lanes keep their
-// half-finished queries. Per step the wave runs box tests until every busy lane stands on a primitive /
+// Rays of one launch form a pool; every wave pulls rays from it (large pools: through one shared cursor, 256
+// rays per atomic; small pools: a fixed share per wave) and keeps its lanes busy: a lane whose query has finished
+// stores its result and, as soon as enough lanes of the wave are idle, the idle lanes take new rays together
+// while the other lanes keep their half-finished queries. Per step the wave runs box tests until every busy lane stands on a primitive /
 // wrapper / medium entry, then handles those entries. This removes the two big sources of idle lanes of a
 // one-ray-per-thread loop: waiting for the longest query of the wave, and box tests interleaved with
 // primitive tests.
