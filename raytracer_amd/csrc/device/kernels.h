@@ -433,24 +433,163 @@ RT_D void add_radiance(const PathState& P, uint32_t slot, V3 add) {
     P.lr[slot] += add.x; P.lg[slot] += add.y; P.lb[slot] += add.z;
 }
 
+// What shading a hit involves, as a sort key: 0 = miss, else 1 + material kind * 32 + texture kind * 8 + primitive
+// kind. The last bin is reserved for "no ray".
+constexpr uint32_t SORT_BINS = 192u;                      // 3 per lane of the wave that scans them
+constexpr uint32_t SORT_ROUNDS = 8u;                      // records per thread and window
+constexpr uint32_t SORT_WINDOW = SHADE_BLOCK * SORT_ROUNDS;
 template <class SC>
+RT_D uint32_t shade_key(const SC& S, uint32_t ref) {
+    if (ref == RT_MISS) return 0u;
+    Cand c;
+    c.t = 0.0; c.ref = ref; c.aux = 0u;
+    const auto M = S.materials + hit_material(S, c);
+    const uint32_t mkind = M->kind;
+    const uint32_t tkind = material_has_texture(mkind) ? S.textures[M->tex].kind : 0u;
+    return 1u + mkind * 32u + tkind * 8u + ((ref & 15u) - 1u);
+}
+
+// One path at its hit (or miss): adds what it gathers to its radiance columns; returns true with the next ray in
+// (no, nd) and the updated throughput T when the path goes on.
+template <class SC>
+RT_D bool shade_one(const SC& S, const RenderConst& C, const PathState& P, uint32_t bounce, V3 o, V3 d, double tm, uint32_t slot,
+                    uint4 h, V3& T, V3& no, V3& nd) {
+    Cand best;
+    best.t = __hiloint2double((int)h.y, (int)h.x); best.ref = h.z; best.aux = h.w;
+    if (best.ref == RT_MISS) {
+        add_radiance(P, slot, elemul(T, v3p(C.bg)));  // src/color.rs:41-43
+        return false;
+    }
+    const auto M = S.materials + hit_material(S, best);
+    const uint32_t mkind = M->kind;
+    const bool textured = material_has_texture(mkind);
+    const bool want_uv = textured && S.textures[M->tex].kind == RT_T_IMAGE;
+    HitRec rec;
+    build_hit_record(S, o, d, tm, best, rec, want_uv);
+    V3 texv = v3(0.0, 0.0, 0.0);
+    if (textured) texv = texture_value(S, M->tex, rec.u, rec.v, rec.p);
+    if (mkind == RT_M_DIFFUSE_LIGHT) add_radiance(P, slot, elemul(T, texv));  // emitted, :50 (zero for every other material)
+    rt::Rng rng;
+    rng.set_path(C.seed, slot % C.npix, C.sample0 + slot / C.npix, bounce, rt::RNG_SCATTER);
+    V3 attenuation = v3(0.0, 0.0, 0.0), dout = v3(1.0, 1.0, 1.0);
+    if (!material_scatter(M, d, rec, texv, rng, attenuation, dout)) return false;  // :52-57
+    T = elemul(T, attenuation);
+    no = rec.p;
+    nd = dout;
+    return bounce + 1u < C.max_depth;  // ray_color(depth - 1) returns black at depth 0 (:37-39)
+}
+
+// Where a shading wave writes its survivors: consecutive records of a range it reserves `chunk` records at a time
+// (one atomic per reservation; chunk = 0: exactly what each round needs).
+struct SurvivorOut {
+    RayRec* next;
+    uint32_t* next_count;
+    uint32_t chunk, o_next, o_end, survivors;
+    RT_D void emit(bool alive, uint32_t lane, V3 no, V3 nd, double tm, uint32_t slot, V3 T) {
+        const unsigned long long mask = __ballot(alive);
+        if (!mask) return;
+        const uint32_t cnt = (uint32_t)__popcll(mask);
+        const uint32_t avail = o_end - o_next;
+        uint32_t base = 0u;
+        if (avail < cnt) {
+            const uint32_t want = cnt - avail > chunk ? cnt - avail : chunk;
+            if (lane == 0u) base = atomicAdd(next_count, want);
+            base = __shfl(base, 0, 64);
+            o_end = base + want;
+        }
+        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (alive) store_ray(next + (rank < avail ? o_next + rank : base + (rank - avail)), no, nd, tm, slot, T);
+        o_next = avail < cnt ? base + (cnt - avail) : o_next + cnt;
+        survivors += cnt;
+    }
+    // pads the unused part of the last reservation and reports the survivors
+    RT_D void finish(uint32_t lane, unsigned long long* ray_total) {
+        for (uint32_t k = o_next + lane; k < o_end; k += 64u) next[k].slot = DEAD_SLOT;
+        if (lane == 0u && survivors) atomicAdd(ray_total, (unsigned long long)survivors);
+    }
+};
+
+template <bool SORT, class SC>
 RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
                     unsigned long long* __restrict__ ray_total) {
     const uint32_t n = bounce == 0u ? C.n_slots : counts[cur];
-    uint32_t* next_count = counts + (cur ^ 1u);
     const RayRec* recs = P.rec[cur];
-    RayRec* next = P.rec[cur ^ 1u];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (bounce == 0u) atomicAdd(ray_total, (unsigned long long)n);  // later bounces: counted as survivors below
         counts[2] = 0u;  // ray cursor of the next extend launch
     }
-    const uint32_t stride = gridDim.x * SHADE_BLOCK;
     const uint32_t lane = threadIdx.x & 63u;
-    // Output records are reserved in chunks: [o_next, o_end) is what the wave still holds (wave-uniform).
     const uint32_t total_waves = gridDim.x * (SHADE_BLOCK / 64u);
-    const uint32_t chunk = n / total_waves >= OUT_MIN_CHUNKS * OUT_CHUNK ? OUT_CHUNK : 0u;
-    uint32_t o_next = 0u, o_end = 0u, survivors = 0u;
-    // every lane of a wave runs the same number of iterations so that the ballot below sees whole waves
+    SurvivorOut out;
+    out.next = P.rec[cur ^ 1u];
+    out.next_count = counts + (cur ^ 1u);
+    out.chunk = n / total_waves >= OUT_MIN_CHUNKS * OUT_CHUNK ? OUT_CHUNK : 0u;
+    out.o_next = 0u; out.o_end = 0u; out.survivors = 0u;
+  if constexpr (SORT) {
+    // Scenes with many kinds of material: every workgroup walks windows of SORT_WINDOW records. The rays of a window are sorted by what shading them
+    // involves (counting sort in LDS) and handed out 64 at a time to whichever wave is free, so that a wave mostly
+    // runs one branch of shade_one instead of all of them.
+    __shared__ uint32_t s_hist[2][SORT_BINS];
+    __shared__ uint16_t s_perm[2][SORT_WINDOW];
+    __shared__ uint32_t s_next_chunk[2];
+    if (threadIdx.x < SORT_BINS) { s_hist[0][threadIdx.x] = 0u; s_hist[1][threadIdx.x] = 0u; }
+    if (threadIdx.x < 2u) s_next_chunk[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t round = 0u;
+    for (uint32_t base = blockIdx.x * SORT_WINDOW; base < n; base += gridDim.x * SORT_WINDOW, ++round) {
+        uint32_t* hist = s_hist[round & 1u];
+        uint16_t* perm = s_perm[round & 1u];
+        uint32_t keys[SORT_ROUNDS], ranks[SORT_ROUNDS];
+#pragma unroll
+        for (uint32_t k = 0; k < SORT_ROUNDS; ++k) {
+            const uint32_t i = base + k * SHADE_BLOCK + threadIdx.x;
+            uint32_t key = SORT_BINS - 1u;  // no ray: beyond n, or a padding record
+            if (i < n && recs[i].slot != DEAD_SLOT) key = shade_key(S, P.hit[i].ref);
+            keys[k] = key;
+            ranks[k] = atomicAdd(&hist[key], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64u) {  // exclusive prefix sum over the bins, three bins per lane of the first wave
+            const uint32_t a = hist[3u * threadIdx.x], b = hist[3u * threadIdx.x + 1u], c = hist[3u * threadIdx.x + 2u];
+            uint32_t incl = a + b + c;
+            for (uint32_t dlt = 1u; dlt < 64u; dlt <<= 1) {
+                const uint32_t t = __shfl_up(incl, dlt, 64);
+                if (threadIdx.x >= dlt) incl += t;
+            }
+            const uint32_t excl = incl - (a + b + c);
+            hist[3u * threadIdx.x] = excl; hist[3u * threadIdx.x + 1u] = excl + a; hist[3u * threadIdx.x + 2u] = excl + a + b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < SORT_ROUNDS; ++k) perm[hist[keys[k]] + ranks[k]] = (uint16_t)(k * SHADE_BLOCK + threadIdx.x);
+        // the other set of bins and the other chunk counter are free again: every wave is past their last use
+        if (threadIdx.x < SORT_BINS) s_hist[(round & 1u) ^ 1u][threadIdx.x] = 0u;
+        if (threadIdx.x == 0u) s_next_chunk[(round & 1u) ^ 1u] = 0u;
+        __syncthreads();
+        const uint32_t n_valid = hist[SORT_BINS - 1u];  // lanes at or past the start of the last bin have no ray
+        for (;;) {
+            uint32_t c = 0u;
+            if (lane == 0u) c = atomicAdd(&s_next_chunk[round & 1u], 1u);
+            c = __shfl(c, 0, 64);
+            if (c * 64u >= n_valid) break;
+            const uint32_t j = c * 64u + lane;
+            bool alive = false;
+            V3 no = v3(0.0, 0.0, 0.0), nd = no, T = no, o = no, d = no;
+            double tm = 0.0;
+            uint32_t slot = DEAD_SLOT;
+            if (j < n_valid) {
+                const uint32_t i = base + perm[j];
+                load_ray64(recs + i, o, d, tm, slot);
+                load_throughput(recs + i, T);
+                const uint4 h = *reinterpret_cast<const uint4*>(P.hit + i);
+                alive = shade_one(S, C, P, bounce, o, d, tm, slot, h, T, no, nd);
+            }
+            out.emit(alive, lane, no, nd, tm, slot, T);
+        }
+    }
+  } else {
+    const uint32_t stride = gridDim.x * SHADE_BLOCK;
+    // every lane of a wave runs the same number of iterations so that the ballot of emit() sees whole waves
     const uint32_t n_round = (n + 63u) & ~63u;
     // The record and hit of the next round are requested before the current round is shaded, so that their trip to
     // HBM overlaps the arithmetic (two waves per SIMD cannot hide it otherwise).
@@ -467,7 +606,6 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
         }
     }
     for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_round; i += stride) {
-        bool alive = false;
         V3 no = v3(0.0, 0.0, 0.0), nd = no;
         const V3 o = o_n, d = d_n;
         V3 T = T_n;
@@ -480,70 +618,28 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
             load_throughput(recs + i + stride, T_n);
             h_n = *reinterpret_cast<const uint4*>(P.hit + i + stride);
         }
-        if (slot != DEAD_SLOT) {
-            Cand best;
-            best.t = __hiloint2double((int)h.y, (int)h.x); best.ref = h.z; best.aux = h.w;
-            if (best.ref == RT_MISS) {
-                add_radiance(P, slot, elemul(T, v3p(C.bg)));  // src/color.rs:41-43
-            } else {
-                const auto M = S.materials + hit_material(S, best);
-                const uint32_t mkind = M->kind;
-                const bool textured = material_has_texture(mkind);
-                const bool want_uv = textured && S.textures[M->tex].kind == RT_T_IMAGE;
-                HitRec rec;
-                build_hit_record(S, o, d, tm, best, rec, want_uv);
-                V3 texv = v3(0.0, 0.0, 0.0);
-                if (textured) texv = texture_value(S, M->tex, rec.u, rec.v, rec.p);
-                if (mkind == RT_M_DIFFUSE_LIGHT) {  // emitted, :50 (zero for every other material)
-                    add_radiance(P, slot, elemul(T, texv));
-                }
-                rt::Rng rng;
-                rng.set_path(C.seed, slot % C.npix, C.sample0 + slot / C.npix, bounce, rt::RNG_SCATTER);
-                V3 attenuation = v3(0.0, 0.0, 0.0), dout = v3(1.0, 1.0, 1.0);
-                if (material_scatter(M, d, rec, texv, rng, attenuation, dout)) {  // :52-57
-                    T = elemul(T, attenuation);
-                    alive = bounce + 1u < C.max_depth;  // ray_color(depth - 1) returns black at depth 0 (:37-39)
-                    no = rec.p;
-                    nd = dout;
-                }
-            }
-        }
-        // compaction: survivors of a wave land in consecutive records of the wave's reserved range; when the
-        // range runs short one atomic reserves the missing records plus (with many rays) a whole chunk
-        const unsigned long long mask = __ballot(alive);
-        if (mask) {
-            const uint32_t cnt = (uint32_t)__popcll(mask);
-            const uint32_t avail = o_end - o_next;
-            uint32_t base = 0u;
-            if (avail < cnt) {
-                const uint32_t want = cnt - avail > chunk ? cnt - avail : chunk;
-                if (lane == 0u) base = atomicAdd(next_count, want);
-                base = __shfl(base, 0, 64);
-                o_end = base + want;
-            }
-            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            if (alive) store_ray(next + (rank < avail ? o_next + rank : base + (rank - avail)), no, nd, tm, slot, T);
-            o_next = avail < cnt ? base + (cnt - avail) : o_next + cnt;
-            survivors += cnt;
-        }
+        const bool alive = slot != DEAD_SLOT && shade_one(S, C, P, bounce, o, d, tm, slot, h, T, no, nd);
+        out.emit(alive, lane, no, nd, tm, slot, T);
     }
-    // pad the unused part of the last chunk
-    for (uint32_t k = o_next + lane; k < o_end; k += 64u) next[k].slot = DEAD_SLOT;
-    if (lane == 0u && survivors) atomicAdd(ray_total, (unsigned long long)survivors);
+  }
+    out.finish(lane, ray_total);
 }
 
-template <bool LDS>
+// LDS bytes the sorting variant of the shade kernel declares for itself (bins, permutations, chunk counters)
+constexpr uint32_t SHADE_SORT_LDS = 2u * SORT_BINS * 4u + 2u * SORT_WINDOW * 2u + 16u;
+
+template <bool LDS, bool SORT>
 __global__ void __launch_bounds__(SHADE_BLOCK, RT_SHADE_WAVES) k_shade(DevScene S0, LdsPlan plan, RenderConst C, PathState P,
                                                                        uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
                                                                        unsigned long long* __restrict__ ray_total) {
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
-        shade_all(S, C, P, counts, cur, bounce, ray_total);
+        shade_all<SORT>(S, C, P, counts, cur, bounce, ray_total);
     } else if (plan_is_empty(plan)) {
-        shade_all(S0, C, P, counts, cur, bounce, ray_total);
+        shade_all<SORT>(S0, C, P, counts, cur, bounce, ray_total);
     } else {
         const DevScene S = stage_scene_partial(S0, plan);
-        shade_all(S, C, P, counts, cur, bounce, ray_total);
+        shade_all<SORT>(S, C, P, counts, cur, bounce, ray_total);
     }
 }
 
