@@ -436,7 +436,10 @@ RT_D void add_radiance(const PathState& P, uint32_t slot, V3 add) {
 // What shading a hit involves, as a sort key: 0 = miss, else 1 + material kind * 32 + texture kind * 8 + primitive
 // kind. The last bin is reserved for "no ray".
 constexpr uint32_t SORT_BINS = 192u;                      // 3 per lane of the wave that scans them
-constexpr uint32_t SORT_ROUNDS = 8u;                      // records per thread and window
+#ifndef RT_SORT_ROUNDS
+#define RT_SORT_ROUNDS 8
+#endif
+constexpr uint32_t SORT_ROUNDS = RT_SORT_ROUNDS;                      // records per thread and window
 constexpr uint32_t SORT_WINDOW = SHADE_BLOCK * SORT_ROUNDS;
 template <class SC>
 RT_D uint32_t shade_key(const SC& S, uint32_t ref) {
@@ -567,23 +570,39 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
         if (threadIdx.x == 0u) s_next_chunk[(round & 1u) ^ 1u] = 0u;
         __syncthreads();
         const uint32_t n_valid = hist[SORT_BINS - 1u];  // lanes at or past the start of the last bin have no ray
-        for (;;) {
+        // chunks of 64 sorted rays, taken from a shared counter; the records of the next chunk are requested before
+        // the current one is shaded
+        auto grab = [&]() {
             uint32_t c = 0u;
             if (lane == 0u) c = atomicAdd(&s_next_chunk[round & 1u], 1u);
-            c = __shfl(c, 0, 64);
-            if (c * 64u >= n_valid) break;
+            return (uint32_t)__shfl(c, 0, 64);
+        };
+        V3 o_n = v3(0.0, 0.0, 0.0), d_n = o_n, T_n = o_n;
+        double tm_n = 0.0;
+        uint32_t slot_n = DEAD_SLOT;
+        uint4 h_n = make_uint4(0u, 0u, RT_MISS, 0u);
+        auto request = [&](uint32_t c) {
             const uint32_t j = c * 64u + lane;
-            bool alive = false;
-            V3 no = v3(0.0, 0.0, 0.0), nd = no, T = no, o = no, d = no;
-            double tm = 0.0;
-            uint32_t slot = DEAD_SLOT;
+            slot_n = DEAD_SLOT;
             if (j < n_valid) {
                 const uint32_t i = base + perm[j];
-                load_ray64(recs + i, o, d, tm, slot);
-                load_throughput(recs + i, T);
-                const uint4 h = *reinterpret_cast<const uint4*>(P.hit + i);
-                alive = shade_one(S, C, P, bounce, o, d, tm, slot, h, T, no, nd);
+                load_ray64(recs + i, o_n, d_n, tm_n, slot_n);
+                load_throughput(recs + i, T_n);
+                h_n = *reinterpret_cast<const uint4*>(P.hit + i);
             }
+        };
+        uint32_t c = grab();
+        request(c);
+        while (c * 64u < n_valid) {
+            V3 no = v3(0.0, 0.0, 0.0), nd = no;
+            const V3 o = o_n, d = d_n;
+            V3 T = T_n;
+            const double tm = tm_n;
+            const uint32_t slot = slot_n;
+            const uint4 h = h_n;
+            c = grab();
+            request(c);
+            const bool alive = slot != DEAD_SLOT && shade_one(S, C, P, bounce, o, d, tm, slot, h, T, no, nd);
             out.emit(alive, lane, no, nd, tm, slot, T);
         }
     }

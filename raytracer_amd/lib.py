@@ -3,7 +3,9 @@
 There is no CPU fallback: if the shared library is missing, or no GPU is present
 when a device call is made, the call raises."""
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -32,11 +34,34 @@ class RtError(RuntimeError):
     pass
 
 
+def _share_the_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64. A process that loads the system runtime first
+    (through librt_hip.so) and PyTorch afterwards ends up with torch refusing to see the GPU ("No HIP GPUs are
+    available"); the other order works, because librt_hip.so then binds to the runtime torch brought. So when torch
+    is installed but not imported yet, its runtime is loaded first; device buffers and streams made by torch can
+    then be handed to rt_render_device / rt_trace_closest_device whichever module is imported first."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 class Library:
     def __init__(self, path=LIB_PATH):
         if not os.path.exists(path):
             raise RtError("%s is missing: build it with `make -C raytracer_amd/csrc` "
                           "(or __graft_entry__.build()); there is no fallback path" % path)
+        _share_the_hip_runtime_with_torch()
         self.lib = C.CDLL(path)
         L = self.lib
         L.rt_last_error.restype = C.c_char_p
