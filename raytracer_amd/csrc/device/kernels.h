@@ -196,7 +196,7 @@ constexpr uint32_t OUT_CHUNK = RT_OUT_CHUNK;  // output records a shading wave r
 #endif
 constexpr uint32_t OUT_MIN_CHUNKS = RT_OUT_MIN_CHUNKS;  // ... "many" = at least this many chunks of input per wave
 
-template <bool COUNT, class SC, class IO>
+template <bool COUNT, bool BOXMEDIA, class SC, class IO>
 RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
     Work work;
     if (COUNT) { work.entries = 0; for (int k = 0; k < 9; ++k) work.prim[k] = 0; }
@@ -218,7 +218,7 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
         c_next = wave_id * share < n ? wave_id * share : n;
         c_end = c_next + share < n ? c_next + share : n;
     }
-    Walker<COUNT> w;
+    Walker<COUNT, BOXMEDIA> w;
     w.done = true;
     typename IO::Ray ray;
     uint32_t index = 0u;
@@ -344,12 +344,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK, 2) k_trace(DevScene S0, LdsPlan p
     io.rays = rays; io.n_rays = n; io.seed = seed; io.hits = hits; io.recs = recs;
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
-        extend_pool<COUNT>(S, io, cursor, work_out);
+        extend_pool<COUNT, false>(S, io, cursor, work_out);
     } else if (plan_is_empty(plan)) {
-        extend_pool<COUNT>(S0, io, cursor, work_out);
+        extend_pool<COUNT, false>(S0, io, cursor, work_out);
     } else {
         const DevScene S = stage_scene_partial(S0, plan);
-        extend_pool<COUNT>(S, io, cursor, work_out);
+        extend_pool<COUNT, false>(S, io, cursor, work_out);
     }
 }
 
@@ -404,7 +404,7 @@ struct ExtendIO {
 
 // counts[0], counts[1]: lengths of the two record arrays; counts[2]: the ray cursor of this launch (zero on
 // entry, reset by the shade launch that follows).
-template <bool COUNT, bool LDS>
+template <bool COUNT, bool LDS, bool BOXMEDIA>
 __global__ void __launch_bounds__(LDS ? EXT_BLOCK : EXT_BLOCK_GLOBAL, LDS ? RT_EXTEND_WAVES : RT_EXTEND_WAVES_GLOBAL) k_extend(DevScene S0, LdsPlan plan, RenderConst C, PathState P,
                                                                        uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
                                                                        unsigned long long* __restrict__ work_out) {
@@ -414,12 +414,12 @@ __global__ void __launch_bounds__(LDS ? EXT_BLOCK : EXT_BLOCK_GLOBAL, LDS ? RT_E
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[cur ^ 1u] = 0u;  // the array the following shade launch appends to
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
-        extend_pool<COUNT>(S, io, counts + 2, work_out);
+        extend_pool<COUNT, BOXMEDIA>(S, io, counts + 2, work_out);
     } else if (plan_is_empty(plan)) {
-        extend_pool<COUNT>(S0, io, counts + 2, work_out);
+        extend_pool<COUNT, BOXMEDIA>(S0, io, counts + 2, work_out);
     } else {
         const DevScene S = stage_scene_partial(S0, plan);
-        extend_pool<COUNT>(S, io, counts + 2, work_out);
+        extend_pool<COUNT, BOXMEDIA>(S, io, counts + 2, work_out);
     }
 }
 

@@ -231,9 +231,8 @@ RT_D bool rect_hit(PR r, const Seg& g, double tmin, double tmax, double& t_out) 
 // Box6::hit -> HittableList::hit over the six sides in src/box6.rs:22-71 order, each against the
 // running closest t (src/hittable.rs:151-164). Returns the side index of the last accepted side.
 template <class PB>
-RT_D bool box6_hit(PB b, const Seg& g, double tmin, double& tmax, uint32_t& side_out) {
+RT_D bool box6_hit(PB b, V3 o, V3 d, double tmin, double& tmax, uint32_t& side_out) {
     const V3 p0 = v3p(b->p0), p1 = v3p(b->p1);
-    const V3 o = g.o, d = g.d;
     bool any = false;
     double t;
     if (rect_t(p1.z, p0.x, p1.x, p0.y, p1.y, o.z, d.z, o.x, d.x, o.y, d.y, tmin, tmax, t)) { tmax = t; side_out = 0u; any = true; }
@@ -308,7 +307,9 @@ RT_D bool diag_first_lane() { return (int)__lane_id() == __ffsll((unsigned long 
 // the end of that range the medium is resolved against the parked result and the world walk resumes at `link`.
 // Wrappers inside a boundary are entered and left like anywhere else, so at the end of the range the ray is back
 // in the medium's own space. The flattener rejects media inside a boundary: one level of parking is enough.
-template <bool COUNT>
+// BOXMEDIA: the scene has a ConstantMedium whose boundary is a (wrapped) box of six sides; only then is the code that
+// answers both boundary queries of such a medium in one step compiled in (it costs registers everywhere else).
+template <bool COUNT, bool BOXMEDIA = false>
 struct Walker {
     Seg g;
     double tm, tmin0, tmin;
@@ -328,6 +329,15 @@ struct Walker {
         i = 0u; end = S.n_nodes; cur_xf = 0u; mode = 0u;
         out_t = 0.0; t_enter = 0.0; out_ref = 0u; out_aux = 0u; med_meta = 0u; med_begin = 0u;
         done = false;
+    }
+
+    // Entries (i, link) of the medium entry the lane stands on are: k wrapper enters, one box of six sides, k exits.
+    template <class SC>
+    RT_D bool wrapped_box_boundary(const SC& S, uint32_t first) const {
+        uint32_t j = i + 1u, m = first;
+        while ((m & 15u) == RT_N_XF_ENTER && j + 1u < nb.w) m = S.nodes[++j].meta;
+        const uint32_t wrappers = j - (i + 1u);
+        return (m & 15u) == RT_N_BOX6 && nb.w == i + 2u + 2u * wrappers;
     }
 
     // ConstantMedium::hit after its two boundary queries, src/constant_medium.rs:52-88
@@ -425,7 +435,7 @@ struct Walker {
                 RT_DIAG_LEAF(RT_N_BOX6)
                 uint32_t side = 0u;
                 double t = best.t;
-                if (box6_hit(S.boxes + idx, g, tmin, t, side)) { best.t = t; best.ref = meta; best.aux = side | (cur_xf << 8); }
+                if (box6_hit(S.boxes + idx, g.o, g.d, tmin, t, side)) { best.t = t; best.ref = meta; best.aux = side | (cur_xf << 8); }
                 break;
             }
             case RT_N_TRIANGLE: {
@@ -488,6 +498,31 @@ struct Walker {
                     const bool inside = sphere_boundary(S.spheres + (first >> 4), g, t1, t2, queries);
 #ifndef RT_DIAG_WAVE
                     if (COUNT) { work->entries += queries; work->prim[RT_N_SPHERE] += queries; }
+#endif
+                    if (inside) resolve_medium(S, key, meta, t1, t2);
+                    i = nb.w;
+                } else if (BOXMEDIA && wrapped_box_boundary(S, first)) {
+                    // boundary is one box of six sides inside zero or more wrappers (src/main.rs:558-582): the ray is
+                    // taken into the box's space once and both queries (src/constant_medium.rs:41-47) are made there
+                    V3 o = g.o, d = g.d;
+                    uint32_t j = i + 1u;
+                    for (uint32_t m = S.nodes[j].meta; (m & 15u) == RT_N_XF_ENTER; m = S.nodes[++j].meta) xf_apply(S.xforms + (m >> 4), o, d);
+                    const auto b = S.boxes + (S.nodes[j].meta >> 4);
+                    uint32_t side = 0u, queries = 1u;
+                    double t1 = D_INF, t2 = D_INF;
+                    bool inside = box6_hit(b, o, d, -D_INF, t1, side);
+                    if (inside) {
+                        queries = 2u;
+                        inside = box6_hit(b, o, d, t1 + 0.0001, t2, side);
+                    }
+#ifndef RT_DIAG_WAVE
+                    if (COUNT) {
+                        const uint32_t wrappers = j - (i + 1u);
+                        work->entries += queries * (2u * wrappers + 1u);
+                        work->prim[RT_N_BOX6] += queries;
+                        work->prim[RT_N_XF_ENTER] += queries * wrappers;
+                        work->prim[RT_N_XF_EXIT] += queries * wrappers;
+                    }
 #endif
                     if (inside) resolve_medium(S, key, meta, t1, t2);
                     i = nb.w;

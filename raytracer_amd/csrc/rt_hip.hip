@@ -55,6 +55,7 @@ struct RtScene {
     uint32_t grid_shade = 256;
     bool extend_lds = false, shade_lds = false;  // which variant of each kernel this scene runs
     bool shade_sort = false;
+    bool box_media = false;   // some ConstantMedium is bounded by a (wrapped) box of six sides
 };
 
 namespace {
@@ -268,13 +269,18 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
             {
                 const dim3 eg(s->grid_extend), eb(s->extend_lds ? rtd::EXT_BLOCK : rtd::EXT_BLOCK_GLOBAL);
                 unsigned long long* wk = work ? w.ray_total + 1 : nullptr;
-                if (s->extend_lds) {
-                    if (work) hipLaunchKernelGGL((rtd::k_extend<true, true>), eg, eb, s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
-                    else hipLaunchKernelGGL((rtd::k_extend<false, true>), eg, eb, s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
-                } else {
-                    if (work) hipLaunchKernelGGL((rtd::k_extend<true, false>), eg, eb, s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
-                    else hipLaunchKernelGGL((rtd::k_extend<false, false>), eg, eb, s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk);
+#define RT_LAUNCH_EXTEND(W, L, B) hipLaunchKernelGGL((rtd::k_extend<W, L, B>), eg, eb, s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk)
+                switch ((work ? 4 : 0) | (s->extend_lds ? 2 : 0) | (s->box_media ? 1 : 0)) {
+                    case 0: RT_LAUNCH_EXTEND(false, false, false); break;
+                    case 1: RT_LAUNCH_EXTEND(false, false, true); break;
+                    case 2: RT_LAUNCH_EXTEND(false, true, false); break;
+                    case 3: RT_LAUNCH_EXTEND(false, true, true); break;
+                    case 4: RT_LAUNCH_EXTEND(true, false, false); break;
+                    case 5: RT_LAUNCH_EXTEND(true, false, true); break;
+                    case 6: RT_LAUNCH_EXTEND(true, true, false); break;
+                    default: RT_LAUNCH_EXTEND(true, true, true); break;
                 }
+#undef RT_LAUNCH_EXTEND
             }
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
             {
@@ -339,6 +345,12 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) { rc = rt::set_error(RT_E_DEVICE, "hipGetDeviceProperties failed"); break; }
         s->n_cus = (uint32_t)std::max(1, prop.multiProcessorCount);
+        for (uint64_t i = 0; i < d->n_nodes && !s->box_media; ++i) {
+            if ((d->nodes[i].meta & 15u) != RT_N_MEDIUM) continue;
+            uint64_t j = i + 1;
+            while (j + 1 < d->nodes[i].link && (d->nodes[j].meta & 15u) == RT_N_XF_ENTER) ++j;
+            s->box_media = (d->nodes[j].meta & 15u) == RT_N_BOX6 && d->nodes[i].link == i + 2 + 2 * (j - (i + 1));
+        }
         // LDS plans: a kernel runs its LDS variant when every table it reads (all but images / texels) fits
         {
             const uint32_t kBudget = 144u * 1024u;  // of the 160 KiB of a CU; one workgroup per CU
@@ -417,16 +429,20 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
                 s->lds_bytes_shade = used;
             }
             const int big = (int)kBudget;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortBudget);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortBudget);
             (void)hipGetLastError();  // a refused attribute must not surface as the error of a later launch
@@ -436,8 +452,8 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
         }
         int per_cu = 0;
-        hipError_t oe = s->extend_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, true>, rtd::EXT_BLOCK, s->lds_bytes)
-                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, false>, rtd::EXT_BLOCK_GLOBAL, s->lds_bytes);
+        hipError_t oe = s->extend_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, true, false>, rtd::EXT_BLOCK, s->lds_bytes)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, false, false>, rtd::EXT_BLOCK_GLOBAL, s->lds_bytes);
         if (oe != hipSuccess || per_cu < 1) per_cu = 1;
         s->grid_extend = s->n_cus * (uint32_t)per_cu;
         int shade_per_cu = 0;

@@ -206,3 +206,26 @@ def test_large_batch_equals_small_batches_and_converges(gpu):
     assert rel < 0.12, rel
     ds.close()
     hs.close()
+
+
+def test_box_bounded_media_follow_the_oracle_path_for_path(gpu, orc):
+    # Cornell smoke: both media are bounded by a box inside Translate(RotateY(..)) (src/main.rs:558-582). The render
+    # kernels answer the two boundary queries of such a medium in one step; the stand-alone trace kernel walks the
+    # boundary's entries like any other. Both must follow the oracle: same rays, same image, same traversal work.
+    import torch
+    hs, ds, osc, su, cam = setup_pair(gpu, orc, 8)
+    W = H = 64
+    spp = 8
+    p = lib.make_params(W, H, 0, spp, list(su.background), seed=SEED)
+    acc_o, ost, _ = orc.render(osc, cam, p, mode=oracle.AABB_TIGHT, threads=8)
+    acc_g, st = ds.render(cam, p)
+    assert abs(int(st.rays) - ost["rays"]) <= 0.002 * ost["rays"]  # a log10 ulp can flip a medium hit now and then
+    rel = np.abs(acc_g - acc_o).sum() / acc_o.sum()
+    assert rel < 0.02, rel
+    dev = torch.zeros(H, W, 3, dtype=torch.float32, device="cuda")
+    wst, work = ds.render_work(cam, p, dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(dev.cpu().numpy(), acc_g)  # the instrumented kernels render the same image
+    for mine, theirs in (("inner", "box_tests"), ("box6", "box6"), ("medium", "medium")):
+        assert abs(work[mine] - ost[theirs]) <= 0.004 * ost[theirs], (mine, work[mine], ost[theirs])
+    assert abs(work["rect"] - (ost["rect"] - 6 * ost["box6"])) <= 0.004 * ost["rect"]
+    ds.close(); hs.close(); orc.api.scene_free(osc)
