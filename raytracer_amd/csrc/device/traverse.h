@@ -307,8 +307,9 @@ RT_D bool diag_first_lane() { return (int)__lane_id() == __ffsll((unsigned long 
 // the end of that range the medium is resolved against the parked result and the world walk resumes at `link`.
 // Wrappers inside a boundary are entered and left like anywhere else, so at the end of the range the ray is back
 // in the medium's own space. The flattener rejects media inside a boundary: one level of parking is enough.
-// BOXMEDIA: the scene has a ConstantMedium whose boundary is a (wrapped) box of six sides; only then is the code that
-// answers both boundary queries of such a medium in one step compiled in (it costs registers everywhere else).
+// BOXMEDIA: the scene has a box of six sides alone inside wrappers, on its own or as the boundary of a ConstantMedium;
+// only then is the code compiled in that handles such a box in one step, in its own space, without entering and
+// leaving the wrappers (it costs registers everywhere else).
 template <bool COUNT, bool BOXMEDIA = false>
 struct Walker {
     Seg g;
@@ -446,6 +447,35 @@ struct Walker {
             }
             case RT_N_XF_ENTER: {
                 RT_DIAG_LEAF(RT_N_XF_ENTER)
+                if constexpr (BOXMEDIA) {
+                    // wrappers around nothing but one box of six sides (src/main.rs:497-515): the ray is taken into
+                    // the box's space for this one test and the walker's own ray is left alone
+                    uint32_t j = i, m = meta, wrappers = 0u;
+                    while ((m & 15u) == RT_N_XF_ENTER && j + 1u < end) { m = S.nodes[++j].meta; ++wrappers; }
+                    bool alone = (m & 15u) == RT_N_BOX6 && j + wrappers < end;
+                    for (uint32_t k = 1u; alone && k <= wrappers; ++k) alone = (S.nodes[j + k].meta & 15u) == RT_N_XF_EXIT;
+                    if (alone) {
+                        V3 o = g.o, d = g.d;
+                        uint32_t inner = idx;
+                        for (uint32_t k = 0u; k < wrappers; ++k) {
+                            inner = S.nodes[i + k].meta >> 4;
+                            xf_apply(S.xforms + inner, o, d);
+                        }
+                        uint32_t side = 0u;
+                        double t = best.t;
+                        if (box6_hit(S.boxes + (m >> 4), o, d, tmin, t, side)) { best.t = t; best.ref = m; best.aux = side | ((inner + 1u) << 8); }
+#ifndef RT_DIAG_WAVE
+                        if (COUNT) {
+                            work->entries += 2u * wrappers;
+                            work->prim[RT_N_XF_ENTER] += wrappers - 1u;
+                            work->prim[RT_N_BOX6] += 1u;
+                            work->prim[RT_N_XF_EXIT] += wrappers;
+                        }
+#endif
+                        i = j + wrappers;  // the last exit; the common ++i below steps past it
+                        break;
+                    }
+                }
                 // a run of wrappers (Translate around RotateY, src/main.rs:690-696) is entered in one step
                 uint32_t xi = idx;
                 for (;;) {

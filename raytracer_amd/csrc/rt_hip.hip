@@ -55,7 +55,7 @@ struct RtScene {
     uint32_t grid_shade = 256;
     bool extend_lds = false, shade_lds = false;  // which variant of each kernel this scene runs
     bool shade_sort = false;
-    bool box_media = false;   // some ConstantMedium is bounded by a (wrapped) box of six sides
+    bool box_media = false;   // some box of six sides sits alone inside wrappers (on its own or as a medium's boundary)
 };
 
 namespace {
@@ -345,11 +345,14 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) { rc = rt::set_error(RT_E_DEVICE, "hipGetDeviceProperties failed"); break; }
         s->n_cus = (uint32_t)std::max(1, prop.multiProcessorCount);
-        for (uint64_t i = 0; i < d->n_nodes && !s->box_media; ++i) {
-            if ((d->nodes[i].meta & 15u) != RT_N_MEDIUM) continue;
-            uint64_t j = i + 1;
-            while (j + 1 < d->nodes[i].link && (d->nodes[j].meta & 15u) == RT_N_XF_ENTER) ++j;
-            s->box_media = (d->nodes[j].meta & 15u) == RT_N_BOX6 && d->nodes[i].link == i + 2 + 2 * (j - (i + 1));
+        for (uint64_t i = 0; i + 1 < d->n_nodes && !s->box_media; ++i) {  // a box of six sides alone inside wrappers?
+            const uint32_t kind = d->nodes[i].meta & 15u;
+            if (kind != RT_N_XF_ENTER || (i > 0 && (d->nodes[i - 1].meta & 15u) == RT_N_XF_ENTER)) continue;
+            uint64_t j = i, wrappers = 0;
+            while (j + 1 < d->n_nodes && (d->nodes[j].meta & 15u) == RT_N_XF_ENTER) { ++j; ++wrappers; }
+            bool alone = (d->nodes[j].meta & 15u) == RT_N_BOX6 && j + wrappers < d->n_nodes;
+            for (uint64_t k = 1; alone && k <= wrappers; ++k) alone = (d->nodes[j + k].meta & 15u) == RT_N_XF_EXIT;
+            s->box_media = alone;
         }
         // LDS plans: a kernel runs its LDS variant when every table it reads (all but images / texels) fits
         {
