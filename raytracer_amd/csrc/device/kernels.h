@@ -83,7 +83,8 @@ constexpr int BLOCK = 256;
 #define RT_EXTEND_WAVES_GLOBAL 3
 #endif
 constexpr int EXT_BLOCK_GLOBAL = RT_EXT_BLOCK_GLOBAL;  // extend when the tables stay in global memory
-constexpr int EXT_BLOCK = 768;    // extend: one 12-wave workgroup per CU sharing one LDS copy of the scene tables
+constexpr int EXT_BLOCK = 768;    // extend: one 12-wave workgroup per CU sharing one LDS copy of the scene tables ...
+constexpr int EXT_BLOCK_LEAN = 1024;  // ... or 16 waves when the walker needs no more than 128 registers (see Walker)
 constexpr int TRACE_BLOCK = 512;  // rt_trace_*: also rebuilds the hit record, needs more registers per lane
 constexpr int SHADE_BLOCK = 512;  // shade: 8 waves per workgroup share the LDS copy of primitive / material / texture tables
 
@@ -196,7 +197,7 @@ constexpr uint32_t OUT_CHUNK = RT_OUT_CHUNK;  // output records a shading wave r
 #endif
 constexpr uint32_t OUT_MIN_CHUNKS = RT_OUT_MIN_CHUNKS;  // ... "many" = at least this many chunks of input per wave
 
-template <bool COUNT, bool BOXMEDIA, class SC, class IO>
+template <bool COUNT, bool BOXMEDIA, bool GENERAL, class SC, class IO>
 RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
     Work work;
     if (COUNT) { work.entries = 0; for (int k = 0; k < 9; ++k) work.prim[k] = 0; }
@@ -218,7 +219,7 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
         c_next = wave_id * share < n ? wave_id * share : n;
         c_end = c_next + share < n ? c_next + share : n;
     }
-    Walker<COUNT, BOXMEDIA> w;
+    Walker<COUNT, BOXMEDIA, GENERAL> w;
     w.done = true;
     typename IO::Ray ray;
     uint32_t index = 0u;
@@ -344,12 +345,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK, 2) k_trace(DevScene S0, LdsPlan p
     io.rays = rays; io.n_rays = n; io.seed = seed; io.hits = hits; io.recs = recs;
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
-        extend_pool<COUNT, false>(S, io, cursor, work_out);
+        extend_pool<COUNT, false, true>(S, io, cursor, work_out);
     } else if (plan_is_empty(plan)) {
-        extend_pool<COUNT, false>(S0, io, cursor, work_out);
+        extend_pool<COUNT, false, true>(S0, io, cursor, work_out);
     } else {
         const DevScene S = stage_scene_partial(S0, plan);
-        extend_pool<COUNT, false>(S, io, cursor, work_out);
+        extend_pool<COUNT, false, true>(S, io, cursor, work_out);
     }
 }
 
@@ -404,8 +405,13 @@ struct ExtendIO {
 
 // counts[0], counts[1]: lengths of the two record arrays; counts[2]: the ray cursor of this launch (zero on
 // entry, reset by the shade launch that follows).
-template <bool COUNT, bool LDS, bool BOXMEDIA>
-__global__ void __launch_bounds__(LDS ? EXT_BLOCK : EXT_BLOCK_GLOBAL, LDS ? RT_EXTEND_WAVES : RT_EXTEND_WAVES_GLOBAL) k_extend(DevScene S0, LdsPlan plan, RenderConst C, PathState P,
+// PROFILE: 0 = scenes without boxes alone inside wrappers and without media that need the general boundary walk,
+// 1 = with such boxes, 3 = with both (see Walker). Profiles 0 and 1 run 16 waves per CU, profile 3 runs 12.
+constexpr int extend_block(bool lds, int profile) { return (profile & 2) ? (lds ? EXT_BLOCK : EXT_BLOCK_GLOBAL) : EXT_BLOCK_LEAN; }
+constexpr int extend_waves(bool lds, int profile) { return (profile & 2) ? (lds ? RT_EXTEND_WAVES : RT_EXTEND_WAVES_GLOBAL) : 4; }
+
+template <bool COUNT, bool LDS, int PROFILE>
+__global__ void __launch_bounds__(extend_block(LDS, PROFILE), extend_waves(LDS, PROFILE)) k_extend(DevScene S0, LdsPlan plan, RenderConst C, PathState P,
                                                                        uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
                                                                        unsigned long long* __restrict__ work_out) {
     ExtendIO io;
@@ -414,12 +420,12 @@ __global__ void __launch_bounds__(LDS ? EXT_BLOCK : EXT_BLOCK_GLOBAL, LDS ? RT_E
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[cur ^ 1u] = 0u;  // the array the following shade launch appends to
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
-        extend_pool<COUNT, BOXMEDIA>(S, io, counts + 2, work_out);
+        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0>(S, io, counts + 2, work_out);
     } else if (plan_is_empty(plan)) {
-        extend_pool<COUNT, BOXMEDIA>(S0, io, counts + 2, work_out);
+        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0>(S0, io, counts + 2, work_out);
     } else {
         const DevScene S = stage_scene_partial(S0, plan);
-        extend_pool<COUNT, BOXMEDIA>(S, io, counts + 2, work_out);
+        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0>(S, io, counts + 2, work_out);
     }
 }
 

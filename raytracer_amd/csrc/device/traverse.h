@@ -310,7 +310,10 @@ RT_D bool diag_first_lane() { return (int)__lane_id() == __ffsll((unsigned long 
 // BOXMEDIA: the scene has a box of six sides alone inside wrappers, on its own or as the boundary of a ConstantMedium;
 // only then is the code compiled in that handles such a box in one step, in its own space, without entering and
 // leaving the wrappers (it costs registers everywhere else).
-template <bool COUNT, bool BOXMEDIA = false>
+// GENERAL: the scene has a ConstantMedium whose boundary is anything else than one sphere or one (wrapped) box, so the
+// re-entrant boundary walk (modes 1 and 2 and the parked world result) is needed. Without it the walker fits 128
+// registers and the kernel runs four waves per SIMD instead of three.
+template <bool COUNT, bool BOXMEDIA = false, bool GENERAL = true>
 struct Walker {
     Seg g;
     double tm, tmin0, tmin;
@@ -383,7 +386,7 @@ struct Walker {
                 if (leaf_found) return;
             }
             // i >= end: the end of the world, or of a boundary query (`end` is then the medium's link)
-            if (mode == 0u) { done = true; return; }
+            if (!GENERAL || mode == 0u) { done = true; return; }
             if (mode == 1u && best.ref != RT_MISS) {
                 t_enter = best.t;
                 tmin = best.t + 0.0001;  // src/constant_medium.rs:45
@@ -556,6 +559,8 @@ struct Walker {
 #endif
                     if (inside) resolve_medium(S, key, meta, t1, t2);
                     i = nb.w;
+                } else if (!GENERAL) {
+                    i = nb.w;  // not reached: the host picks this variant only for scenes without such media
                 } else {
                     out_t = best.t; out_ref = best.ref; out_aux = best.aux;
                     med_meta = meta;

@@ -56,6 +56,7 @@ struct RtScene {
     bool extend_lds = false, shade_lds = false;  // which variant of each kernel this scene runs
     bool shade_sort = false;
     bool box_media = false;   // some box of six sides sits alone inside wrappers (on its own or as a medium's boundary)
+    int profile = 3;          // extend kernel profile: bit 0 = box_media, bit 1 = a medium needs the general boundary walk
 };
 
 namespace {
@@ -267,18 +268,22 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
             const uint32_t cur = bounce & 1u;
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
             {
-                const dim3 eg(s->grid_extend), eb(s->extend_lds ? rtd::EXT_BLOCK : rtd::EXT_BLOCK_GLOBAL);
+                const dim3 eg(s->grid_extend);
                 unsigned long long* wk = work ? w.ray_total + 1 : nullptr;
-#define RT_LAUNCH_EXTEND(W, L, B) hipLaunchKernelGGL((rtd::k_extend<W, L, B>), eg, eb, s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk)
-                switch ((work ? 4 : 0) | (s->extend_lds ? 2 : 0) | (s->box_media ? 1 : 0)) {
-                    case 0: RT_LAUNCH_EXTEND(false, false, false); break;
-                    case 1: RT_LAUNCH_EXTEND(false, false, true); break;
-                    case 2: RT_LAUNCH_EXTEND(false, true, false); break;
-                    case 3: RT_LAUNCH_EXTEND(false, true, true); break;
-                    case 4: RT_LAUNCH_EXTEND(true, false, false); break;
-                    case 5: RT_LAUNCH_EXTEND(true, false, true); break;
-                    case 6: RT_LAUNCH_EXTEND(true, true, false); break;
-                    default: RT_LAUNCH_EXTEND(true, true, true); break;
+#define RT_LAUNCH_EXTEND(W, L, PR) hipLaunchKernelGGL((rtd::k_extend<W, L, PR>), eg, dim3(rtd::extend_block(L, PR)), s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk)
+                switch ((work ? 8 : 0) | (s->extend_lds ? 4 : 0) | s->profile) {
+                    case 0: RT_LAUNCH_EXTEND(false, false, 0); break;
+                    case 1: RT_LAUNCH_EXTEND(false, false, 1); break;
+                    case 3: RT_LAUNCH_EXTEND(false, false, 3); break;
+                    case 4: RT_LAUNCH_EXTEND(false, true, 0); break;
+                    case 5: RT_LAUNCH_EXTEND(false, true, 1); break;
+                    case 7: RT_LAUNCH_EXTEND(false, true, 3); break;
+                    case 8: RT_LAUNCH_EXTEND(true, false, 0); break;
+                    case 9: RT_LAUNCH_EXTEND(true, false, 1); break;
+                    case 11: RT_LAUNCH_EXTEND(true, false, 3); break;
+                    case 12: RT_LAUNCH_EXTEND(true, true, 0); break;
+                    case 13: RT_LAUNCH_EXTEND(true, true, 1); break;
+                    default: RT_LAUNCH_EXTEND(true, true, 3); break;
                 }
 #undef RT_LAUNCH_EXTEND
             }
@@ -354,6 +359,18 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
             for (uint64_t k = 1; alone && k <= wrappers; ++k) alone = (d->nodes[j + k].meta & 15u) == RT_N_XF_EXIT;
             s->box_media = alone;
         }
+        bool general_media = false;  // a medium whose boundary is neither one sphere nor one box alone inside wrappers
+        for (uint64_t i = 0; i < d->n_nodes && !general_media; ++i) {
+            if ((d->nodes[i].meta & 15u) != RT_N_MEDIUM) continue;
+            const uint64_t link = d->nodes[i].link;
+            if (link == i + 2 && (d->nodes[i + 1].meta & 15u) == RT_N_SPHERE) continue;
+            uint64_t j = i + 1;
+            while (j + 1 < link && (d->nodes[j].meta & 15u) == RT_N_XF_ENTER) ++j;
+            const bool boxed = (d->nodes[j].meta & 15u) == RT_N_BOX6 && link == i + 2 + 2 * (j - (i + 1));
+            if (!boxed) general_media = true;
+        }
+        s->profile = general_media ? 3 : (s->box_media ? 1 : 0);
+        if (general_media) s->box_media = true;  // profile 3 compiles both in
         // LDS plans: a kernel runs its LDS variant when every table it reads (all but images / texels) fits
         {
             const uint32_t kBudget = 144u * 1024u;  // of the 160 KiB of a CU; one workgroup per CU
@@ -432,20 +449,18 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
                 s->lds_bytes_shade = used;
             }
             const int big = (int)kBudget;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+#define RT_BIG_LDS(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, big)
+            RT_BIG_LDS((rtd::k_extend<false, false, 0>)); RT_BIG_LDS((rtd::k_extend<false, false, 1>)); RT_BIG_LDS((rtd::k_extend<false, false, 3>));
+            RT_BIG_LDS((rtd::k_extend<false, true, 0>)); RT_BIG_LDS((rtd::k_extend<false, true, 1>)); RT_BIG_LDS((rtd::k_extend<false, true, 3>));
+            RT_BIG_LDS((rtd::k_extend<true, false, 0>)); RT_BIG_LDS((rtd::k_extend<true, false, 1>)); RT_BIG_LDS((rtd::k_extend<true, false, 3>));
+            RT_BIG_LDS((rtd::k_extend<true, true, 0>)); RT_BIG_LDS((rtd::k_extend<true, true, 1>)); RT_BIG_LDS((rtd::k_extend<true, true, 3>));
+#undef RT_BIG_LDS
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortBudget);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_extend<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortBudget);
             (void)hipGetLastError();  // a refused attribute must not surface as the error of a later launch
@@ -455,8 +470,17 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
         }
         int per_cu = 0;
-        hipError_t oe = s->extend_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, true, false>, rtd::EXT_BLOCK, s->lds_bytes)
-                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, false, false>, rtd::EXT_BLOCK_GLOBAL, s->lds_bytes);
+        hipError_t oe = hipErrorUnknown;
+#define RT_OCC(L, PR) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, L, PR>, rtd::extend_block(L, PR), s->lds_bytes)
+        switch ((s->extend_lds ? 4 : 0) | s->profile) {
+            case 0: RT_OCC(false, 0); break;
+            case 1: RT_OCC(false, 1); break;
+            case 3: RT_OCC(false, 3); break;
+            case 4: RT_OCC(true, 0); break;
+            case 5: RT_OCC(true, 1); break;
+            default: RT_OCC(true, 3); break;
+        }
+#undef RT_OCC
         if (oe != hipSuccess || per_cu < 1) per_cu = 1;
         s->grid_extend = s->n_cus * (uint32_t)per_cu;
         int shade_per_cu = 0;
