@@ -197,7 +197,7 @@ constexpr uint32_t OUT_CHUNK = RT_OUT_CHUNK;  // output records a shading wave r
 #endif
 constexpr uint32_t OUT_MIN_CHUNKS = RT_OUT_MIN_CHUNKS;  // ... "many" = at least this many chunks of input per wave
 
-template <bool COUNT, bool BOXMEDIA, bool GENERAL, class SC, class IO>
+template <bool COUNT, bool BOXMEDIA, bool GENERAL, uint32_t VOTE_DEN, class SC, class IO>
 RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
     Work work;
     if (COUNT) { work.entries = 0; for (int k = 0; k < 9; ++k) work.prim[k] = 0; }
@@ -269,8 +269,7 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
             continue;
         }
         if (busy) {
-            w.box_run(S, ray.key, &work);
-            if (!w.done) w.leaf(S, ray.rs, ray.key, &work);
+            if (w.template box_run<VOTE_DEN>(S, ray.key, &work)) w.leaf(S, ray.rs, ray.key, &work);
             if (w.done) {
                 busy = false;
                 pending = true;
@@ -345,12 +344,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK, 2) k_trace(DevScene S0, LdsPlan p
     io.rays = rays; io.n_rays = n; io.seed = seed; io.hits = hits; io.recs = recs;
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
-        extend_pool<COUNT, false, true>(S, io, cursor, work_out);
+        extend_pool<COUNT, false, true, 0u>(S, io, cursor, work_out);
     } else if (plan_is_empty(plan)) {
-        extend_pool<COUNT, false, true>(S0, io, cursor, work_out);
+        extend_pool<COUNT, false, true, 0u>(S0, io, cursor, work_out);
     } else {
         const DevScene S = stage_scene_partial(S0, plan);
-        extend_pool<COUNT, false, true>(S, io, cursor, work_out);
+        extend_pool<COUNT, false, true, 0u>(S, io, cursor, work_out);
     }
 }
 
@@ -405,8 +404,9 @@ struct ExtendIO {
 
 // counts[0], counts[1]: lengths of the two record arrays; counts[2]: the ray cursor of this launch (zero on
 // entry, reset by the shade launch that follows).
-// PROFILE: 0 = scenes without boxes alone inside wrappers and without media that need the general boundary walk,
-// 1 = with such boxes, 3 = with both (see Walker). Profiles 0 and 1 run 16 waves per CU, profile 3 runs 12.
+// PROFILE bits: 1 = the scene has boxes alone inside wrappers, 2 = it has media that need the general boundary walk
+// (set together with 1), 4 = lanes leave the box phase by vote (entry streams of 128 entries and more); see Walker.
+// Without bit 2 the kernel runs 16 waves per CU, with it 12.
 constexpr int extend_block(bool lds, int profile) { return (profile & 2) ? (lds ? EXT_BLOCK : EXT_BLOCK_GLOBAL) : EXT_BLOCK_LEAN; }
 constexpr int extend_waves(bool lds, int profile) { return (profile & 2) ? (lds ? RT_EXTEND_WAVES : RT_EXTEND_WAVES_GLOBAL) : 4; }
 
@@ -420,12 +420,12 @@ __global__ void __launch_bounds__(extend_block(LDS, PROFILE), extend_waves(LDS, 
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[cur ^ 1u] = 0u;  // the array the following shade launch appends to
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
-        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0>(S, io, counts + 2, work_out);
+        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? 4u : 0u>(S, io, counts + 2, work_out);
     } else if (plan_is_empty(plan)) {
-        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0>(S0, io, counts + 2, work_out);
+        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? 4u : 0u>(S0, io, counts + 2, work_out);
     } else {
         const DevScene S = stage_scene_partial(S0, plan);
-        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0>(S, io, counts + 2, work_out);
+        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? 4u : 0u>(S, io, counts + 2, work_out);
     }
 }
 

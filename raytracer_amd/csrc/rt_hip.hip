@@ -56,7 +56,7 @@ struct RtScene {
     bool extend_lds = false, shade_lds = false;  // which variant of each kernel this scene runs
     bool shade_sort = false;
     bool box_media = false;   // some box of six sides sits alone inside wrappers (on its own or as a medium's boundary)
-    int profile = 3;          // extend kernel profile: bit 0 = box_media, bit 1 = a medium needs the general boundary walk
+    int profile = 3;          // extend kernel profile (bits as in kernels.h): 1 box_media, 2 general boundary walk, 4 vote
 };
 
 namespace {
@@ -271,20 +271,17 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
                 const dim3 eg(s->grid_extend);
                 unsigned long long* wk = work ? w.ray_total + 1 : nullptr;
 #define RT_LAUNCH_EXTEND(W, L, PR) hipLaunchKernelGGL((rtd::k_extend<W, L, PR>), eg, dim3(rtd::extend_block(L, PR)), s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk)
-                switch ((work ? 8 : 0) | (s->extend_lds ? 4 : 0) | s->profile) {
-                    case 0: RT_LAUNCH_EXTEND(false, false, 0); break;
-                    case 1: RT_LAUNCH_EXTEND(false, false, 1); break;
-                    case 3: RT_LAUNCH_EXTEND(false, false, 3); break;
-                    case 4: RT_LAUNCH_EXTEND(false, true, 0); break;
-                    case 5: RT_LAUNCH_EXTEND(false, true, 1); break;
-                    case 7: RT_LAUNCH_EXTEND(false, true, 3); break;
-                    case 8: RT_LAUNCH_EXTEND(true, false, 0); break;
-                    case 9: RT_LAUNCH_EXTEND(true, false, 1); break;
-                    case 11: RT_LAUNCH_EXTEND(true, false, 3); break;
-                    case 12: RT_LAUNCH_EXTEND(true, true, 0); break;
-                    case 13: RT_LAUNCH_EXTEND(true, true, 1); break;
-                    default: RT_LAUNCH_EXTEND(true, true, 3); break;
+#define RT_LAUNCH_EXTEND_P(PR) do { if (work) { if (s->extend_lds) RT_LAUNCH_EXTEND(true, true, PR); else RT_LAUNCH_EXTEND(true, false, PR); } \
+                                    else { if (s->extend_lds) RT_LAUNCH_EXTEND(false, true, PR); else RT_LAUNCH_EXTEND(false, false, PR); } } while (0)
+                switch (s->profile) {
+                    case 0: RT_LAUNCH_EXTEND_P(0); break;
+                    case 1: RT_LAUNCH_EXTEND_P(1); break;
+                    case 3: RT_LAUNCH_EXTEND_P(3); break;
+                    case 4: RT_LAUNCH_EXTEND_P(4); break;
+                    case 5: RT_LAUNCH_EXTEND_P(5); break;
+                    default: RT_LAUNCH_EXTEND_P(7); break;
                 }
+#undef RT_LAUNCH_EXTEND_P
 #undef RT_LAUNCH_EXTEND
             }
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
@@ -369,7 +366,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
             const bool boxed = (d->nodes[j].meta & 15u) == RT_N_BOX6 && link == i + 2 + 2 * (j - (i + 1));
             if (!boxed) general_media = true;
         }
-        s->profile = general_media ? 3 : (s->box_media ? 1 : 0);
+        s->profile = (general_media ? 3 : (s->box_media ? 1 : 0)) | (d->n_nodes >= 128 ? 4 : 0);
         if (general_media) s->box_media = true;  // profile 3 compiles both in
         // LDS plans: a kernel runs its LDS variant when every table it reads (all but images / texels) fits
         {
@@ -450,10 +447,10 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
             }
             const int big = (int)kBudget;
 #define RT_BIG_LDS(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, big)
-            RT_BIG_LDS((rtd::k_extend<false, false, 0>)); RT_BIG_LDS((rtd::k_extend<false, false, 1>)); RT_BIG_LDS((rtd::k_extend<false, false, 3>));
-            RT_BIG_LDS((rtd::k_extend<false, true, 0>)); RT_BIG_LDS((rtd::k_extend<false, true, 1>)); RT_BIG_LDS((rtd::k_extend<false, true, 3>));
-            RT_BIG_LDS((rtd::k_extend<true, false, 0>)); RT_BIG_LDS((rtd::k_extend<true, false, 1>)); RT_BIG_LDS((rtd::k_extend<true, false, 3>));
-            RT_BIG_LDS((rtd::k_extend<true, true, 0>)); RT_BIG_LDS((rtd::k_extend<true, true, 1>)); RT_BIG_LDS((rtd::k_extend<true, true, 3>));
+#define RT_BIG_LDS_P(PR) RT_BIG_LDS((rtd::k_extend<false, false, PR>)); RT_BIG_LDS((rtd::k_extend<false, true, PR>)); \
+                         RT_BIG_LDS((rtd::k_extend<true, false, PR>)); RT_BIG_LDS((rtd::k_extend<true, true, PR>))
+            RT_BIG_LDS_P(0); RT_BIG_LDS_P(1); RT_BIG_LDS_P(3); RT_BIG_LDS_P(4); RT_BIG_LDS_P(5); RT_BIG_LDS_P(7);
+#undef RT_BIG_LDS_P
 #undef RT_BIG_LDS
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortBudget);
@@ -472,14 +469,16 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         int per_cu = 0;
         hipError_t oe = hipErrorUnknown;
 #define RT_OCC(L, PR) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_extend<false, L, PR>, rtd::extend_block(L, PR), s->lds_bytes)
-        switch ((s->extend_lds ? 4 : 0) | s->profile) {
-            case 0: RT_OCC(false, 0); break;
-            case 1: RT_OCC(false, 1); break;
-            case 3: RT_OCC(false, 3); break;
-            case 4: RT_OCC(true, 0); break;
-            case 5: RT_OCC(true, 1); break;
-            default: RT_OCC(true, 3); break;
+#define RT_OCC_P(PR) do { if (s->extend_lds) RT_OCC(true, PR); else RT_OCC(false, PR); } while (0)
+        switch (s->profile) {
+            case 0: RT_OCC_P(0); break;
+            case 1: RT_OCC_P(1); break;
+            case 3: RT_OCC_P(3); break;
+            case 4: RT_OCC_P(4); break;
+            case 5: RT_OCC_P(5); break;
+            default: RT_OCC_P(7); break;
         }
+#undef RT_OCC_P
 #undef RT_OCC
         if (oe != hipSuccess || per_cu < 1) per_cu = 1;
         s->grid_extend = s->n_cus * (uint32_t)per_cu;
