@@ -180,6 +180,9 @@ RT_D bool plan_is_empty(const LdsPlan& p) {
 #define RT_REFILL_LANES 32
 #endif
 constexpr uint32_t REFILL_LANES = RT_REFILL_LANES;  // refill when at least this many lanes are idle
+#ifndef RT_VOTE_DEN
+#define RT_VOTE_DEN 4u
+#endif
 #ifndef RT_RAY_CHUNK
 #define RT_RAY_CHUNK 256
 #endif
@@ -420,12 +423,12 @@ __global__ void __launch_bounds__(extend_block(LDS, PROFILE), extend_waves(LDS, 
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[cur ^ 1u] = 0u;  // the array the following shade launch appends to
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
-        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? 4u : 0u>(S, io, counts + 2, work_out);
+        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? RT_VOTE_DEN : 0u>(S, io, counts + 2, work_out);
     } else if (plan_is_empty(plan)) {
-        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? 4u : 0u>(S0, io, counts + 2, work_out);
+        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? RT_VOTE_DEN : 0u>(S0, io, counts + 2, work_out);
     } else {
         const DevScene S = stage_scene_partial(S0, plan);
-        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? 4u : 0u>(S, io, counts + 2, work_out);
+        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? RT_VOTE_DEN : 0u>(S, io, counts + 2, work_out);
     }
 }
 
