@@ -228,6 +228,32 @@ int rt_resolve_u8(const float* accum_rgb, uint32_t width, uint32_t height, uint6
 int rt_resolve_u8_device(const float* accum_rgb_dev, uint32_t width, uint32_t height, uint64_t spp, uint8_t* rgb_out_dev,
                          void* stream);
 
+/* ---- tree construction on the device ------------------------------------- */
+
+#define RT_BVH_TOKEN_LEAF 0xFu          /* meta of a leaf token (not an RtNodeKind) */
+#define RT_BVH_MAX_OBJECTS (1u << 28)
+
+/* Stands in for BVHNode::new (src/bvh.rs:17-98, a recursive stable sort per
+ * node on the host: O(n log^2 n)) where its tree need not be reproduced: builds
+ * a binary tree over n >= 2 objects on the current HIP device from their
+ * bounding boxes alone. boxes = n x 6 doubles (min x y z, max x y z; what
+ * Hittable::bounding_box, src/hittable.rs:45, returns). The objects are
+ * ordered by the 63-bit Morton code of their box centres (ties: input order)
+ * and the tree is the binary radix tree over the ordered codes; node boxes are
+ * surrounding_box (src/aabb.rs:33-50) of the children's. The result is the
+ * tree in pre-order, 2 n - 1 tokens in `tokens_out` (host memory):
+ *   inner node: lo/hi = box rounded outward to f32 (inverted when flat on an
+ *               axis), meta = RT_N_INNER, link = index of the first token after
+ *               its subtree;
+ *   leaf:       meta = RT_BVH_TOKEN_LEAF, link = position of the object in
+ *               `boxes`.
+ * The caller turns tokens into stream entries by replacing every leaf token
+ * with the entries of that object and rebasing the links. One object per leaf,
+ * left subtree first, as in BVHNode::hit (src/bvh.rs:101-111). Boxes with NaN
+ * or without a finite centre are refused (RT_E_INVALID). `ms_device`, when not
+ * NULL, receives the device time of the build without the copies. */
+int rt_bvh_build(const double* boxes, uint64_t n, RtNode* tokens_out, double* ms_device);
+
 #ifdef __cplusplus
 }
 #endif

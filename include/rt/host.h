@@ -49,6 +49,12 @@ enum RtSceneId {                 /* the `match scene` of src/main.rs:65-162 */
                                           widest instead of the reference's random axis (src/bvh.rs:24): same closest
                                           hits (up to exact ties in t), far fewer boxes visited on large meshes */
 
+#define RT_SCENE_BVH_LBVH 4u           /* every BVHNode over two or more objects is built by rt_bvh_build on the current
+                                          HIP device (Morton order, radix tree) instead of src/bvh.rs:17-98; the scene
+                                          stream moves on by the draws of the replaced builder (the scene's geometry
+                                          stays the same); same closest hits up to exact ties in t.
+                                          Needs a GPU at scene construction; takes precedence over WIDEST_AXIS */
+
 typedef struct RtSceneOptions {
     uint32_t flags;
     uint32_t boxes_per_side;     /* final_scene ground grid (src/main.rs:591); 0 = 20 */
@@ -102,6 +108,7 @@ int rth_constant_medium(RtBuilder* b, int boundary, double density, int tex);  /
 int rth_list_new(RtBuilder* b);                                                /* HittableList::new, src/hittable.rs:129 */
 int rth_list_add(RtBuilder* b, int list, int obj);                             /* HittableList::add, :139 */
 int rth_bvh(RtBuilder* b, int list, double time0, double time1);               /* BVHNode::new, src/bvh.rs:94 */
+int rth_bvh_lbvh(RtBuilder* b, int list, double time0, double time1);        /* same place in the scene, the tree made by rt_bvh_build (two or more objects) */
 int rth_builder_finish(RtBuilder* b, int root, RtHostScene** out);             /* flatten the tree under `root` (a BVHNode) */
 
 #ifdef __cplusplus

@@ -53,6 +53,8 @@ class Oracle:
         L.orc_render.restype = i
         L.orc_harvest.argtypes = [vp, P(abi.RtCamera), P(abi.RtRenderParams), i, u32, u64, u64, vp, P(u64)]
         L.orc_harvest.restype = i
+        L.orc_lbvh_tokens.argtypes = [vp, u64, vp]
+        L.orc_lbvh_tokens.restype = i
 
     # ---- known-answer helpers ------------------------------------------
     def philox(self, ctr, key):
@@ -78,6 +80,14 @@ class Oracle:
         self.lib.orc_resolve_u8(a.ctypes.data_as(C.POINTER(C.c_double)), w, h, spp,
                                 out.ctypes.data_as(C.POINTER(C.c_uint8)))
         return out
+
+    def lbvh_tokens(self, boxes):
+        """The checker of rt_bvh_build: (n, 6) f64 boxes -> (2 n - 1) pre-order tokens."""
+        boxes = np.ascontiguousarray(boxes, dtype=np.float64)
+        assert boxes.ndim == 2 and boxes.shape[1] == 6
+        tokens = np.zeros(max(2 * boxes.shape[0] - 1, 1), dtype=abi.NODE_DTYPE)
+        self.api.check(self.lib.orc_lbvh_tokens(boxes.ctypes.data, boxes.shape[0], tokens.ctypes.data))
+        return tokens
 
     # ---- queries ---------------------------------------------------------
     def trace(self, scene, rays, seed=0x5EED, mode=AABB_TIGHT, records=False):

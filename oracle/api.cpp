@@ -126,10 +126,15 @@ int orc_scene_build(int scene_id, uint64_t seed, const RtSceneOptions* opt, OrcS
     cur_ctx = &s->ctx;
     tls.rng.set_scene(seed);
     bvh_widest_axis = o.bvh_widest_axis;
+    bvh_lbvh = opt && (opt->flags & RT_SCENE_BVH_LBVH) != 0;
     try {
         s->world = build_scene(scene_id, o);
-    } catch (const std::exception& e) { cur_ctx = nullptr; bvh_widest_axis = false; delete s; return fail(RT_E_INVALID, e.what()); }
+    } catch (const std::exception& e) {
+        cur_ctx = nullptr; bvh_widest_axis = false; bvh_lbvh = false; delete s;
+        return fail(RT_E_INVALID, e.what());
+    }
     bvh_widest_axis = false;
+    bvh_lbvh = false;
     cur_ctx = nullptr;
     if (!s->world) { delete s; return fail(RT_E_INVALID, "unknown scene id"); }
     *out = s;
@@ -322,6 +327,22 @@ int orc_list_add(OrcBuilder* b, int list, int obj) {
 }
 int orc_bvh(OrcBuilder* b, int list, double time0, double time1) {
     CHK(b->lists, list) B_ENTER push_obj(b, BVHNode_new(*b->lists[(size_t)list], time0, time1)); B_LEAVE return (int)b->obj.size() - 1;
+}
+int orc_bvh_lbvh(OrcBuilder* b, int list, double time0, double time1) {  // the linear BVH of lbvh.hpp over the list
+    CHK(b->lists, list)
+    B_ENTER
+    if (b->lists[(size_t)list]->objects.size() < 2) throw std::runtime_error("a linear BVH needs at least two objects");
+    push_obj(b, lbvh_from_list(b->lists[(size_t)list]->objects, time0, time1));
+    B_LEAVE return (int)b->obj.size() - 1;
+}
+// the checker for rt_bvh_build: same arguments, same tokens
+int orc_lbvh_tokens(const double* boxes, uint64_t n, RtNode* tokens_out) {
+    if (!boxes || !tokens_out) return fail(RT_E_INVALID, "null argument");
+    try {
+        const std::vector<RtNode> t = orc_lbvh::build_tokens(boxes, (size_t)n);
+        std::memcpy(tokens_out, t.data(), t.size() * sizeof(RtNode));
+    } catch (const std::exception& e) { return fail(RT_E_INVALID, e.what()); }
+    return 0;
 }
 int orc_builder_finish(OrcBuilder* b, int root, OrcScene** out) {
     CHK(b->obj, root)

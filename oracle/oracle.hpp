@@ -39,6 +39,7 @@
 #include <stdexcept>
 #include <vector>
 
+#include "lbvh.hpp"
 #include "philox.hpp"
 
 namespace orc {
@@ -931,8 +932,51 @@ inline std::shared_ptr<BVHNode> new_from_list(std::vector<HitPtr>& objects, size
     temp->fbox = FBox::from(temp->_box);
     return temp;
 }
+
+// Tree policy (not in the reference): true = lists of two or more objects get the linear BVH of lbvh.hpp.
+inline thread_local bool bvh_lbvh = false;
+
+// the object tree that a pre-order token sequence describes; `at` advances past the subtree
+inline HitPtr lbvh_subtree(const std::vector<RtNode>& tokens, size_t& at, const std::vector<HitPtr>& objects, double time0,
+                           double time1) {
+    const RtNode& t = tokens.at(at++);
+    if (t.meta == RT_BVH_TOKEN_LEAF) return objects.at(t.link);
+    auto node = std::make_shared<BVHNode>();
+    node->left = lbvh_subtree(tokens, at, objects, time0, time1);
+    node->right = lbvh_subtree(tokens, at, objects, time0, time1);
+    if (at != t.link) throw std::runtime_error("malformed tree tokens");
+    AABB box_left, box_right;
+    if (!node->left->bounding_box(time0, time1, box_left) || !node->right->bounding_box(time0, time1, box_right))
+        throw std::runtime_error("no bounding box");
+    node->_box = surrounding_box(box_left, box_right);
+    node->fbox = FBox::from(node->_box);
+    for (int a = 0; a < 3; ++a)
+        if (node->fbox.lo[a] != t.lo[a] || node->fbox.hi[a] != t.hi[a]) throw std::runtime_error("token box differs from the node's");
+    return node;
+}
+
+inline std::shared_ptr<BVHNode> lbvh_from_list(const std::vector<HitPtr>& objects, double time0, double time1) {
+    std::vector<double> boxes(objects.size() * 6);
+    for (size_t i = 0; i < objects.size(); ++i) {
+        AABB b;
+        if (!objects[i]->bounding_box(time0, time1, b)) throw std::runtime_error("no bounding box");
+        for (int a = 0; a < 3; ++a) { boxes[6 * i + a] = b._min[a]; boxes[6 * i + 3 + a] = b._max[a]; }
+    }
+    const std::vector<RtNode> tokens = orc_lbvh::build_tokens(boxes.data(), objects.size());
+    size_t at = 0;
+    HitPtr root = lbvh_subtree(tokens, at, objects, time0, time1);
+    return std::static_pointer_cast<BVHNode>(root);
+}
+
 inline std::shared_ptr<BVHNode> BVHNode_new(HittableList& list, double time0, double time1) {  // :94-97
     if (list.objects.empty()) throw std::runtime_error("BVHNode::new on an empty list");
+    if (bvh_lbvh && list.objects.size() >= 2) {
+        // the scene stream moves on as if the reference builder had drawn its axis per node (:24), so that whatever the
+        // scene draws afterwards is the same under either tree policy
+        struct Nodes { static uint64_t of(size_t n) { return n <= 2 ? 1 : 1 + of(n / 2) + of(n - n / 2); } };
+        for (uint64_t k = Nodes::of(list.objects.size()); k > 0; --k) (void)random_int(0, 2);
+        return lbvh_from_list(list.objects, time0, time1);
+    }
     return new_from_list(list.objects, 0, list.objects.size(), time0, time1);
 }
 

@@ -8,6 +8,8 @@ import numpy as np
 RT_MISS = 0xFFFFFFFF
 RT_NONE = 0xFFFFFFFF
 RT_ABI_VERSION = 1
+RT_OK, RT_E_INVALID, RT_E_DEVICE, RT_E_NOMEM, RT_E_UNSUPPORTED = 0, -1, -2, -3, -4
+RT_N_INNER = 0
 
 d3 = C.c_double * 3
 
@@ -128,6 +130,9 @@ class RtSceneSetup(C.Structure):
 
 RT_SCENE_BVH_SHUTTER_TIMES = 1
 RT_SCENE_BVH_WIDEST_AXIS = 2
+RT_SCENE_BVH_LBVH = 4
+RT_BVH_TOKEN_LEAF = 0xF
+RT_BVH_MAX_OBJECTS = 1 << 28
 
 # numpy views of the per-ray structs (same layout, no padding surprises: all members are 4/8-byte aligned)
 RAY_DTYPE = np.dtype([("o", "<f8", 3), ("d", "<f8", 3), ("tm", "<f8"), ("tmin", "<f8"), ("tmax", "<f8"),
@@ -135,6 +140,8 @@ RAY_DTYPE = np.dtype([("o", "<f8", 3), ("d", "<f8", 3), ("tm", "<f8"), ("tmin", 
 HIT_DTYPE = np.dtype([("prim_id", "<u4"), ("sub", "<u4"), ("t", "<f8"), ("u", "<f8"), ("v", "<f8")])
 HITREC_DTYPE = np.dtype([("p", "<f8", 3), ("normal", "<f8", 3), ("t", "<f8"), ("u", "<f8"), ("v", "<f8"),
                          ("prim_id", "<u4"), ("sub", "<u4"), ("mat", "<u4"), ("front_face", "<u4")])
+NODE_DTYPE = np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("meta", "<u4"), ("link", "<u4")])
+assert NODE_DTYPE.itemsize == C.sizeof(RtNode) == 32
 assert RAY_DTYPE.itemsize == C.sizeof(RtRay) == 88
 assert HIT_DTYPE.itemsize == C.sizeof(RtHit) == 32
 assert HITREC_DTYPE.itemsize == C.sizeof(RtHitRecord) == 88

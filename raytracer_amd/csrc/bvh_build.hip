@@ -1,0 +1,358 @@
+// rt_bvh_build: a binary tree over n bounding boxes, built on the device. It stands in for the host recursion of
+// BVHNode::new (src/bvh.rs:17-98) where that tree need not be reproduced: objects ordered by the Morton code of their
+// box centres (Lauterbach et al. 2009), the binary radix tree over the ordered codes built with one thread per inner
+// node (Karras 2012), boxes united bottom-up (src/aabb.rs:33-50), and the tree written out in pre-order.
+//
+// Everything that decides the shape of the tree is exact: centres and their quantisation use + - * / in f64 without
+// contraction, the sort is stable, ties between equal codes are broken by sorted position. A CPU builder following the
+// same definition therefore gives the same tokens bit for bit.
+//
+// Device memory per object: 48 B box in, 2 x 12 B sort keys and values, 28 B tree links, 48 B node box, 64 B tokens.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "../../include/rt/abi.h"
+#include "host/errors.hpp"
+
+namespace bvh {
+
+constexpr int BLOCK = 256;
+constexpr int MAX_DEPTH = 128;           // more than the 96 bits of a key (code, sorted position)
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint32_t RIGHT = 0x80000000u;  // in a parent link: the node is its parent's right child
+constexpr uint32_t LEAF = 0x80000000u;   // in a child link: the child is a leaf
+
+struct Tree {
+    const uint64_t* code;   // n sorted codes
+    const uint32_t* object; // n: object of sorted position
+    uint32_t* child;        // 2 (n - 1): left, right of inner node i (LEAF flag)
+    uint32_t* parent_inner; // n - 1 (RIGHT flag); NONE for the root
+    uint32_t* parent_leaf;  // n
+    uint32_t* first;        // n - 1: first sorted position under inner node i
+    uint32_t* last;         // n - 1
+    uint32_t* split;        // n - 1: last sorted position of the left subtree
+    uint32_t* visits;       // n - 1, zeroed
+    double* node_box;       // (n - 1) x 6
+    uint32_t n;
+};
+
+__device__ inline uint64_t spread21(uint64_t v) {  // bit i -> bit 3 i
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x001F00000000FFFFull;
+    v = (v | (v << 16)) & 0x001F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+__device__ inline double wave_min(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ inline double wave_max(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// least and greatest box centre per axis of this block's share -> partial[block][6]; flags boxes with NaN or
+// without a finite centre
+__global__ __launch_bounds__(BLOCK) void k_centre_bounds(const double* __restrict__ boxes, uint32_t n, double* __restrict__ partial,
+                                                         uint32_t* __restrict__ bad) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool wrong = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK)
+        for (int a = 0; a < 3; ++a) {
+            const double mn = boxes[6 * i + a], mx = boxes[6 * i + 3 + a];
+            const double c = (mn + mx) * 0.5;
+            wrong = wrong || mn != mn || mx != mx || c != c || isinf(c);
+            lo[a] = fmin(lo[a], c);
+            hi[a] = fmax(hi[a], c);
+        }
+    __shared__ double s[BLOCK / 64][6];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int a = 0; a < 3; ++a) {
+        const double l = wave_min(lo[a]), h = wave_max(hi[a]);
+        if (lane == 0) { s[wave][a] = l; s[wave][3 + a] = h; }
+    }
+    if (wrong) *bad = 1u;
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = s[0][threadIdx.x];
+        for (int w = 1; w < BLOCK / 64; ++w) v = threadIdx.x < 3 ? fmin(v, s[w][threadIdx.x]) : fmax(v, s[w][threadIdx.x]);
+        partial[(uint64_t)blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bounds_final(const double* __restrict__ partial, uint32_t blocks, double* __restrict__ bounds) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t b = threadIdx.x; b < blocks; b += BLOCK)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fmin(lo[a], partial[(uint64_t)b * 6 + a]);
+            hi[a] = fmax(hi[a], partial[(uint64_t)b * 6 + 3 + a]);
+        }
+    __shared__ double s[BLOCK / 64][6];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int a = 0; a < 3; ++a) {
+        const double l = wave_min(lo[a]), h = wave_max(hi[a]);
+        if (lane == 0) { s[wave][a] = l; s[wave][3 + a] = h; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = s[0][threadIdx.x];
+        for (int w = 1; w < BLOCK / 64; ++w) v = threadIdx.x < 3 ? fmin(v, s[w][threadIdx.x]) : fmax(v, s[w][threadIdx.x]);
+        bounds[threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_morton(const double* __restrict__ boxes, uint32_t n, const double* __restrict__ bounds,
+                                                  uint64_t* __restrict__ code, uint32_t* __restrict__ object) {
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint64_t q[3];
+    for (int a = 0; a < 3; ++a) {
+        const double c = (boxes[6 * i + a] + boxes[6 * i + 3 + a]) * 0.5;
+        const double lo = bounds[a], ext = bounds[3 + a] - lo;
+        double s = ext > 0.0 ? (c - lo) / ext * 2097152.0 : 0.0;
+        if (!(s < 2097151.0)) s = 2097151.0;
+        if (!(s >= 0.0)) s = 0.0;
+        q[a] = (uint64_t)s;
+    }
+    code[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    object[i] = (uint32_t)i;
+}
+
+// leading bits shared by the keys (code, position) of sorted positions i and j; -1 when j lies outside
+__device__ inline int prefix(const uint64_t* __restrict__ code, uint32_t n, int64_t i, int64_t j) {
+    if (j < 0 || j >= (int64_t)n) return -1;
+    const uint64_t x = code[i] ^ code[j];
+    if (x) return __clzll((long long)x);
+    return 64 + __clz((int)((uint32_t)i ^ (uint32_t)j));
+}
+
+// one thread per inner node: its range of sorted positions, its split and its children (Karras 2012, algorithm 1)
+__global__ __launch_bounds__(BLOCK) void k_radix_tree(Tree t) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t n = t.n;
+    if (i >= (int64_t)n - 1) return;
+    const int64_t d = prefix(t.code, n, i, i + 1) > prefix(t.code, n, i, i - 1) ? 1 : -1;
+    const int below = prefix(t.code, n, i, i - d);
+    int64_t reach = 2;
+    while (prefix(t.code, n, i, i + reach * d) > below) reach *= 2;
+    int64_t len = 0;
+    for (int64_t s = reach / 2; s >= 1; s /= 2)
+        if (prefix(t.code, n, i, i + (len + s) * d) > below) len += s;
+    const int64_t j = i + len * d;
+    const int whole = prefix(t.code, n, i, j);
+    int64_t off = 0, s = len;
+    do {
+        s = (s + 1) / 2;
+        if (prefix(t.code, n, i, i + (off + s) * d) > whole) off += s;
+    } while (s > 1);
+    const int64_t gamma = i + off * d + (d < 0 ? -1 : 0);
+    const int64_t lo = i < j ? i : j, hi = i < j ? j : i;
+    t.first[i] = (uint32_t)lo;
+    t.last[i] = (uint32_t)hi;
+    t.split[i] = (uint32_t)gamma;
+    if (lo == gamma) { t.child[2 * i] = (uint32_t)gamma | LEAF; t.parent_leaf[gamma] = (uint32_t)i; }
+    else { t.child[2 * i] = (uint32_t)gamma; t.parent_inner[gamma] = (uint32_t)i; }
+    if (hi == gamma + 1) { t.child[2 * i + 1] = (uint32_t)(gamma + 1) | LEAF; t.parent_leaf[gamma + 1] = (uint32_t)i | RIGHT; }
+    else { t.child[2 * i + 1] = (uint32_t)(gamma + 1); t.parent_inner[gamma + 1] = (uint32_t)i | RIGHT; }
+    if (i == 0) t.parent_inner[0] = NONE;
+}
+
+// One thread per leaf climbs towards the root; the second thread to reach a node unites the box it carries with the
+// sibling's, which the first thread stored before it left (fence, then the counter).
+__global__ __launch_bounds__(BLOCK) void k_unite_boxes(Tree t, const double* __restrict__ boxes) {
+    const uint64_t leaf = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (leaf >= t.n) return;
+    double mine[6];
+    {
+        const uint64_t o = t.object[leaf];
+        for (int k = 0; k < 6; ++k) mine[k] = boxes[6 * o + k];
+    }
+    uint32_t up = t.parent_leaf[leaf];
+    bool carried_is_leaf = true;
+    uint64_t carried = leaf;
+    for (int depth = 0; depth < MAX_DEPTH; ++depth) {
+        const uint32_t node = up & ~RIGHT;
+        if (!carried_is_leaf) {
+            for (int k = 0; k < 6; ++k) t.node_box[6 * carried + k] = mine[k];
+        }
+        __threadfence();
+        if (atomicAdd(&t.visits[node], 1u) == 0u) return;  // the sibling subtree is not finished: its thread goes on
+        __threadfence();
+        const uint32_t other = t.child[2 * (uint64_t)node + ((up & RIGHT) ? 0 : 1)];
+        double theirs[6];
+        if (other & LEAF) {
+            const uint64_t o = t.object[other & ~LEAF];
+            for (int k = 0; k < 6; ++k) theirs[k] = boxes[6 * o + k];
+        } else {
+            const double* src = t.node_box + 6 * (uint64_t)other;
+            for (int k = 0; k < 6; ++k) theirs[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int k = 0; k < 3; ++k) {
+            mine[k] = fmin(mine[k], theirs[k]);
+            mine[3 + k] = fmax(mine[3 + k], theirs[3 + k]);
+        }
+        carried = node;
+        carried_is_leaf = false;
+        up = t.parent_inner[node];
+        if (up == NONE) {
+            for (int k = 0; k < 6; ++k) t.node_box[6 * (uint64_t)node + k] = mine[k];
+            return;
+        }
+    }
+}
+
+__device__ inline float f32_down(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = nextafterf(f, -INFINITY);
+    return f;
+}
+__device__ inline float f32_up(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = nextafterf(f, INFINITY);
+    return f;
+}
+
+// One thread per node. Pre-order position: the root is token 0; a left child follows its parent; a right child
+// follows the 2 L - 1 tokens of the left subtree (L leaves).
+__global__ __launch_bounds__(BLOCK) void k_tokens(Tree t, RtNode* __restrict__ tokens) {
+    const uint64_t id = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t n = t.n;
+    if (id >= 2ull * n - 1) return;
+    const bool inner = id < n - 1;
+    const uint64_t self = inner ? id : id - (n - 1);
+    uint64_t pos = 0;
+    // keys are 96 bits wide, so no node lies deeper than that; the bound keeps a damaged link from looping for ever
+    int depth = 0;
+    for (uint32_t up = inner ? t.parent_inner[self] : t.parent_leaf[self]; up != NONE && depth < MAX_DEPTH; ++depth) {
+        const uint32_t p = up & ~RIGHT;
+        pos += (up & RIGHT) ? 2ull * (t.split[p] - t.first[p] + 1u) : 1ull;
+        up = t.parent_inner[p];
+    }
+    RtNode out;
+    if (inner) {
+        double b[6];
+        for (int k = 0; k < 6; ++k) b[k] = t.node_box[6 * self + k];
+        const bool flat = b[0] == b[3] || b[1] == b[4] || b[2] == b[5];
+        for (int a = 0; a < 3; ++a) {
+            out.lo[a] = flat ? INFINITY : f32_down(b[a]);
+            out.hi[a] = flat ? -INFINITY : f32_up(b[3 + a]);
+        }
+        out.meta = RT_N_INNER;
+        out.link = (uint32_t)(pos + 2ull * (t.last[self] - t.first[self] + 1u) - 1ull);
+    } else {
+        for (int a = 0; a < 3; ++a) { out.lo[a] = 0.0f; out.hi[a] = 0.0f; }
+        out.meta = RT_BVH_TOKEN_LEAF;
+        out.link = t.object[self];
+    }
+    tokens[pos] = out;
+}
+
+struct DeviceBuffers {  // freed on every way out
+    void* p[16] = {};
+    int used = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~DeviceBuffers() {
+        for (int i = 0; i < used; ++i) (void)hipFree(p[i]);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    template <class T>
+    hipError_t get(T** out, uint64_t count) {
+        void* q = nullptr;
+        const hipError_t e = hipMalloc(&q, count * sizeof(T) + 16);
+        if (e == hipSuccess) { p[used++] = q; *out = (T*)q; }
+        return e;
+    }
+};
+
+}  // namespace bvh
+
+#define BVH_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) {                                                                            \
+            (void)hipGetLastError();                                                                       \
+            return rt::set_error(e_ == hipErrorOutOfMemory ? RT_E_NOMEM : RT_E_DEVICE,                     \
+                                 std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+        }                                                                                                  \
+    } while (0)
+
+extern "C" int rt_bvh_build(const double* boxes, uint64_t n64, RtNode* tokens_out, double* ms_device) {
+    using namespace bvh;
+    if (!boxes || !tokens_out) return rt::set_error(RT_E_INVALID, "null argument");
+    if (n64 < 2) return rt::set_error(RT_E_INVALID, "a tree needs at least two objects");
+    if (n64 > RT_BVH_MAX_OBJECTS) return rt::set_error(RT_E_INVALID, "too many objects for one tree");
+    int device_count = 0;
+    if (hipGetDeviceCount(&device_count) != hipSuccess || device_count < 1) {
+        (void)hipGetLastError();
+        return rt::set_error(RT_E_DEVICE, "building a tree on the device needs a HIP device; there is no CPU path");
+    }
+    const uint32_t n = (uint32_t)n64;
+    const uint32_t inner = n - 1;
+    DeviceBuffers mem;
+    double *d_boxes, *d_partial, *d_bounds, *d_node_box;
+    uint64_t *d_code_in, *d_code;
+    uint32_t *d_obj_in, *d_obj, *d_child, *d_parent_inner, *d_parent_leaf, *d_first, *d_last, *d_split, *d_visits, *d_bad;
+    RtNode* d_tokens;
+    const uint32_t reduce_blocks = (uint32_t)std::min<uint64_t>(1024, (n64 + BLOCK - 1) / BLOCK);
+    BVH_TRY(mem.get(&d_boxes, 6ull * n));
+    BVH_TRY(mem.get(&d_partial, 6ull * reduce_blocks + 6 + 2));
+    BVH_TRY(mem.get(&d_code_in, n));
+    BVH_TRY(mem.get(&d_code, n));
+    BVH_TRY(mem.get(&d_obj_in, n));
+    BVH_TRY(mem.get(&d_obj, n));
+    BVH_TRY(mem.get(&d_child, 2ull * inner));
+    BVH_TRY(mem.get(&d_parent_inner, inner));
+    BVH_TRY(mem.get(&d_parent_leaf, n));
+    BVH_TRY(mem.get(&d_first, 3ull * inner));
+    BVH_TRY(mem.get(&d_visits, inner));
+    BVH_TRY(mem.get(&d_node_box, 6ull * inner));
+    BVH_TRY(mem.get(&d_tokens, 2ull * n - 1));
+    d_bounds = d_partial + 6ull * reduce_blocks;
+    d_bad = (uint32_t*)(d_bounds + 6);
+    d_last = d_first + inner;
+    d_split = d_last + inner;
+    size_t sort_bytes = 0;
+    BVH_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, d_code_in, d_code, d_obj_in, d_obj, (size_t)n, 0u, 63u, (hipStream_t) nullptr));
+    char* d_sort;
+    BVH_TRY(mem.get(&d_sort, sort_bytes));
+    BVH_TRY(hipEventCreate(&mem.e0));
+    BVH_TRY(hipEventCreate(&mem.e1));
+
+    BVH_TRY(hipMemcpy(d_boxes, boxes, 6ull * n * sizeof(double), hipMemcpyHostToDevice));
+    BVH_TRY(hipMemsetAsync(d_visits, 0, (uint64_t)inner * sizeof(uint32_t), nullptr));
+    BVH_TRY(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), nullptr));
+    BVH_TRY(hipEventRecord(mem.e0, nullptr));
+    const uint32_t per_leaf = (n + BLOCK - 1) / BLOCK, per_inner = (inner + BLOCK - 1) / BLOCK;
+    const uint32_t per_node = (uint32_t)((2ull * n - 1 + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_centre_bounds, dim3(reduce_blocks), dim3(BLOCK), 0, nullptr, d_boxes, n, d_partial, d_bad);
+    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(BLOCK), 0, nullptr, d_partial, reduce_blocks, d_bounds);
+    hipLaunchKernelGGL(k_morton, dim3(per_leaf), dim3(BLOCK), 0, nullptr, d_boxes, n, d_bounds, d_code_in, d_obj_in);
+    BVH_TRY(hipGetLastError());
+    BVH_TRY(rocprim::radix_sort_pairs(d_sort, sort_bytes, d_code_in, d_code, d_obj_in, d_obj, (size_t)n, 0u, 63u, (hipStream_t) nullptr));
+    Tree t{d_code, d_obj, d_child, d_parent_inner, d_parent_leaf, d_first, d_last, d_split, d_visits, d_node_box, n};
+    hipLaunchKernelGGL(k_radix_tree, dim3(per_inner), dim3(BLOCK), 0, nullptr, t);
+    hipLaunchKernelGGL(k_unite_boxes, dim3(per_leaf), dim3(BLOCK), 0, nullptr, t, d_boxes);
+    hipLaunchKernelGGL(k_tokens, dim3(per_node), dim3(BLOCK), 0, nullptr, t, d_tokens);
+    BVH_TRY(hipGetLastError());
+    BVH_TRY(hipEventRecord(mem.e1, nullptr));
+    uint32_t bad = 0;
+    BVH_TRY(hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost));
+    if (bad) return rt::set_error(RT_E_INVALID, "a bounding box holds NaN or has no finite centre");
+    BVH_TRY(hipMemcpy(tokens_out, d_tokens, (2ull * n - 1) * sizeof(RtNode), hipMemcpyDeviceToHost));
+    if (ms_device) {
+        float ms = 0.0f;
+        BVH_TRY(hipEventElapsedTime(&ms, mem.e0, mem.e1));
+        *ms_device = ms;
+    }
+    return RT_OK;
+}

@@ -58,6 +58,7 @@ template <class V> bool ok(const V& v, int h) { return h >= 0 && (size_t)h < v.s
 template <class F> int guarded(F&& f) {
     try { return f(); }
     catch (const std::bad_alloc&) { return rt::set_error(RT_E_NOMEM, "out of host memory"); }
+    catch (const AbiError& e) { return rt::set_error(e.code, e.what()); }
     catch (const std::exception& e) { return rt::set_error(RT_E_INVALID, e.what()); }
     catch (...) { return rt::set_error(RT_E_INVALID, "unknown error"); }
 }
@@ -90,10 +91,10 @@ int rth_scene_build(int scene_id, uint64_t seed, const RtSceneOptions* opt, RtHo
         }
         SceneCtx ctx(seed);
         CtxScope scope(&ctx);
-        struct AxisPolicy {  // the split-axis policy applies to this build only, also when it throws
-            explicit AxisPolicy(bool widest) { g_bvh_widest_axis = widest; }
-            ~AxisPolicy() { g_bvh_widest_axis = false; }
-        } policy(o.bvh_widest_axis);
+        struct TreePolicy {  // the tree policy applies to this build only, also when it throws
+            TreePolicy(bool widest, bool device) { g_bvh_widest_axis = widest; g_bvh_device = device; }
+            ~TreePolicy() { g_bvh_widest_axis = false; g_bvh_device = false; }
+        } policy(o.bvh_widest_axis, opt && (opt->flags & RT_SCENE_BVH_LBVH) != 0);
         HitPtr world = build_scene(scene_id, o);
         if (!world) return rt::set_error(RT_E_INVALID, "unknown scene id");
         *out = flatten_root(*world);
@@ -181,6 +182,11 @@ int rth_list_add(RtBuilder* b, int list, int obj) {
 int rth_bvh(RtBuilder* b, int list, double time0, double time1) {
     if (!ok(b->lists, list)) return bad_handle();
     return IN_CTX(add_obj(b, BVHNode::create(*b->lists[(size_t)list], time0, time1)));
+}
+int rth_bvh_lbvh(RtBuilder* b, int list, double time0, double time1) {
+    if (!ok(b->lists, list)) return bad_handle();
+    if (b->lists[(size_t)list]->objects.size() < 2) return rt::set_error(RT_E_INVALID, "a tree built on the device needs at least two objects");
+    return IN_CTX(add_obj(b, std::make_shared<DeviceBvh>(b->lists[(size_t)list]->objects, time0, time1)));
 }
 int rth_builder_finish(RtBuilder* b, int root, RtHostScene** out) {
     if (!out) return rt::set_error(RT_E_INVALID, "null output");

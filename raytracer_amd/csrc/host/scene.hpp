@@ -657,8 +657,62 @@ struct BvhBuild {
     }
 };
 
+// A failure of the library's own C ABI underneath a host call: carries the RtError code through the unwinding.
+struct AbiError : std::runtime_error {
+    int code;
+    AbiError(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+// Tree policy of BVHNode::create. false: the host recursion above. true: lists of two or more objects get the tree
+// that rt_bvh_build makes on the current HIP device.
+inline thread_local bool g_bvh_device = false;
+
+struct DeviceBvh : BVHNode {  // left / right stay empty: the tree is held as pre-order tokens
+    std::vector<HitPtr> objects;
+    std::vector<RtNode> tokens;
+    double ms_device = 0.0;
+
+    DeviceBvh(const std::vector<HitPtr>& list, double time0, double time1) : objects(list) {
+        std::vector<double> boxes(objects.size() * 6);
+        for (size_t i = 0; i < objects.size(); ++i) {
+            AABB b;
+            if (!objects[i]->bounding_box(time0, time1, b)) throw std::runtime_error("object without a bounding box in BVHNode::new");
+            for (int a = 0; a < 3; ++a) { boxes[6 * i + a] = b._min[a]; boxes[6 * i + 3 + a] = b._max[a]; }
+            _box = i ? surrounding_box(_box, b) : b;  // min / max are exact: the same box as the tree's root
+        }
+        tokens.resize(2 * objects.size() - 1);
+        const int rc = rt_bvh_build(boxes.data(), objects.size(), tokens.data(), &ms_device);
+        if (rc != RT_OK) throw AbiError(rc, rt_last_error());
+    }
+    void flatten(Flat& f) const override {
+        std::vector<std::pair<uint32_t, uint32_t>> open;  // (entry, token after its subtree)
+        for (size_t k = 0; k < tokens.size(); ++k) {
+            const RtNode& t = tokens[k];
+            if (t.meta == RT_BVH_TOKEN_LEAF) {
+                objects.at(t.link)->flatten(f);
+            } else {
+                const uint32_t at = f.push_node(RT_N_INNER, 0);
+                for (int a = 0; a < 3; ++a) { f.nodes[at].lo[a] = t.lo[a]; f.nodes[at].hi[a] = t.hi[a]; }
+                open.emplace_back(at, t.link);
+            }
+            while (!open.empty() && open.back().second == k + 1) {
+                f.nodes[open.back().first].link = (uint32_t)f.nodes.size();
+                open.pop_back();
+            }
+        }
+        if (!open.empty()) throw std::runtime_error("malformed tree tokens");
+    }
+};
+
 inline std::shared_ptr<BVHNode> BVHNode::create(HittableList& list, double time0, double time1) {
     if (list.objects.empty()) throw std::invalid_argument("BVHNode::new on an empty list");
+    if (g_bvh_device && list.objects.size() >= 2) {
+        // the scene stream moves on as if the host recursion had drawn its axis per node, so that whatever the scene
+        // draws afterwards is the same under either tree policy
+        BvhBuild counter{list.objects, time0, time1, ctx().rng, false, {}};
+        rng_seek(ctx().rng, rng_position(ctx().rng) + counter.count_draws(list.objects.size()));
+        return std::make_shared<DeviceBvh>(list.objects, time0, time1);
+    }
     BvhBuild b{list.objects, time0, time1, ctx().rng, g_bvh_widest_axis, {}};
     const uint64_t first = rng_position(ctx().rng);
     const uint64_t total = b.count_draws(list.objects.size());

@@ -46,7 +46,7 @@ class SceneApi:
             "xy_rect": [vp, d, d, d, d, d, i], "xz_rect": [vp, d, d, d, d, d, i], "yz_rect": [vp, d, d, d, d, d, i],
             "box6": [vp, d3p, d3p, i], "triangle": [vp, d3p, d3p, d3p, i],
             "translate": [vp, i, d3p], "rotate_y": [vp, i, d], "constant_medium": [vp, i, d, i],
-            "list_new": [vp], "list_add": [vp, i, i], "bvh": [vp, i, d, d], "builder_finish": [vp, i, P(vp)],
+            "list_new": [vp], "list_add": [vp, i, i], "bvh": [vp, i, d, d], "bvh_lbvh": [vp, i, d, d], "builder_finish": [vp, i, P(vp)],
         }
         for name, args in sig.items():
             f = self.fn(name)
@@ -169,6 +169,7 @@ class Builder:
 
     def list_add(self, l, obj): return self._call("list_add", l, obj)
     def bvh(self, lst, t0=0.0, t1=1.0): return self._call("bvh", lst, float(t0), float(t1))
+    def bvh_lbvh(self, lst, t0=0.0, t1=1.0): return self._call("bvh_lbvh", lst, float(t0), float(t1))
 
     def finish(self, root):
         """Returns an opaque scene handle; the builder can be closed afterwards."""

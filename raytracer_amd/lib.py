@@ -19,14 +19,14 @@ ABI_SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_trace_closest",
     "rt_trace_records", "rt_trace_closest_device", "rt_trace_work", "rt_render", "rt_render_device", "rt_render_work",
     "rt_resolve_u8",
-    "rt_resolve_u8_device",
+    "rt_resolve_u8_device", "rt_bvh_build",
 )
 HOST_SYMBOLS = (
     "rth_scene_build", "rth_scene_desc", "rth_scene_setup", "rth_scene_free", "rth_camera_new", "rth_builder_new",
     "rth_builder_free", "rth_tex_solid", "rth_tex_checker", "rth_tex_noise", "rth_tex_image", "rth_mat_lambertian",
     "rth_mat_metal", "rth_mat_dielectric", "rth_mat_diffuse_light", "rth_mat_isotropic", "rth_sphere",
     "rth_moving_sphere", "rth_xy_rect", "rth_xz_rect", "rth_yz_rect", "rth_box6", "rth_triangle", "rth_translate",
-    "rth_rotate_y", "rth_constant_medium", "rth_list_new", "rth_list_add", "rth_bvh", "rth_builder_finish",
+    "rth_rotate_y", "rth_constant_medium", "rth_list_new", "rth_list_add", "rth_bvh", "rth_bvh_lbvh", "rth_builder_finish",
 )
 
 
@@ -84,6 +84,7 @@ class Library:
         L.rt_render_work.argtypes = [vp, P(abi.RtCamera), P(abi.RtRenderParams), vp, vp, P(abi.RtRenderStats), P(u64)]
         L.rt_resolve_u8.argtypes = [vp, u32, u32, u64, vp]
         L.rt_resolve_u8_device.argtypes = [vp, u32, u32, u64, vp, vp]
+        L.rt_bvh_build.argtypes = [vp, u64, vp, P(C.c_double)]
         for name in ABI_SYMBOLS:
             f = getattr(L, name)
             if name not in ("rt_last_error", "rt_abi_version", "rt_scene_destroy"):
@@ -98,6 +99,15 @@ class Library:
 
     def device_count(self):
         return self.lib.rt_device_count()
+
+    def bvh_build(self, boxes):
+        """rt_bvh_build: (n, 6) f64 boxes -> (2 n - 1) pre-order tokens (structured array) and the device time in ms."""
+        boxes = np.ascontiguousarray(boxes, dtype=np.float64)
+        assert boxes.ndim == 2 and boxes.shape[1] == 6
+        tokens = np.zeros(max(2 * boxes.shape[0] - 1, 1), dtype=abi.NODE_DTYPE)
+        ms = C.c_double(0.0)
+        self.check(self.lib.rt_bvh_build(boxes.ctypes.data, boxes.shape[0], tokens.ctypes.data, C.byref(ms)))
+        return tokens, ms.value
 
 
 _LIB = None

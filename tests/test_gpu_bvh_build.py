@@ -1,0 +1,117 @@
+"""rt_bvh_build on the MI355X against the oracle's CPU statement of the same tree: tokens bit for bit, and scenes built
+with it traced against the oracle's scenes built the same way (hits and traversal work). The reference has no such
+builder (it stands in for BVHNode::new, src/bvh.rs:17-98); what is checked is the GPU against the definition."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import SEED, load_golden, scene_kwargs
+from raytracer_amd import abi, lib
+from test_bvh_tokens import box_sets
+from test_gpu_trace import compare_hits
+
+pytestmark = pytest.mark.gpu
+
+
+def same_tokens(a, b):
+    return a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("name,boxes", list(box_sets()), ids=[n for n, _ in box_sets()])
+def test_tokens_equal_the_oracles_small(gpu, orc, name, boxes):
+    got, ms = gpu.bvh_build(boxes)
+    assert same_tokens(got, orc.lbvh_tokens(boxes)), name
+    assert ms > 0.0
+
+
+@pytest.mark.parametrize("n", [100_000, 2_000_000])
+def test_tokens_equal_the_oracles_large(gpu, orc, n):
+    rng = np.random.default_rng(n)
+    c = rng.normal(0.0, 50.0, (n, 3))
+    c[: n // 10] = c[n // 10: 2 * (n // 10)]  # a tenth of the centres twice
+    h = rng.uniform(0.0, 0.5, (n, 3))
+    h[::7, 1] = 0.0  # flat boxes among them
+    boxes = np.concatenate([c - h, c + h], axis=1)
+    got, ms = gpu.bvh_build(boxes)
+    want = orc.lbvh_tokens(boxes)
+    assert same_tokens(got, want)
+    leaves = got["link"][got["meta"] == abi.RT_BVH_TOKEN_LEAF]
+    assert np.array_equal(np.sort(leaves), np.arange(n, dtype=np.uint32))
+    print("rt_bvh_build: %d objects in %.2f ms on the device" % (n, ms))
+
+
+def test_bad_boxes_are_refused(gpu):
+    boxes = np.array([[0, 0, 0, 1, 1, 1], [2, 2, 2, 3, 3, 3], [4, 4, 4, 5, 5, 5]], dtype=np.float64)
+    bad = boxes.copy()
+    bad[1, 2] = np.nan
+    with pytest.raises(lib.RtError, match="NaN"):
+        gpu.bvh_build(bad)
+    bad = boxes.copy()
+    bad[2, 3] = np.inf
+    with pytest.raises(lib.RtError, match="finite centre"):
+        gpu.bvh_build(bad)
+    got, _ = gpu.bvh_build(boxes)  # and the library works afterwards
+    assert (got["meta"] == abi.RT_BVH_TOKEN_LEAF).sum() == 3
+
+
+@pytest.mark.parametrize("sid", [1, 8, 9, 12])
+def test_scene_with_device_built_trees(gpu, orc, sid):
+    g = load_golden(sid)
+    kw = scene_kwargs(sid)
+    flags = abi.RT_SCENE_BVH_LBVH | (abi.RT_SCENE_BVH_SHUTTER_TIMES if sid == 1 else 0)
+    hs = lib.HostScene.build(sid, seed=SEED, flags=flags, **kw)
+    ds = lib.DeviceScene(hs)
+    osc = orc.api.scene_build(sid, seed=SEED, flags=flags, **kw)
+    oh, _, ost = orc.trace(osc, g["rays"], seed=SEED, mode=oracle.AABB_TIGHT)
+    gh, work = ds.trace_work(g["rays"], seed=SEED)
+    compare_hits(oh, gh, "scene %d, trees built on the device" % sid)
+    # the same tree on both sides: exactly the same traversal work
+    assert work["inner"] == ost["box_tests"] and work["triangle"] == ost["triangle"] and work["box6"] == ost["box6"]
+    assert work["sphere"] == ost["sphere"] and work["msphere"] == ost["msphere"]
+    ds.close()
+    hs.close()
+    orc.api.scene_free(osc)
+
+
+def test_mesh_of_a_million_triangles(gpu, orc):
+    kw = dict(n_triangles=1_000_000)
+    hs = lib.HostScene.build(12, seed=SEED, flags=abi.RT_SCENE_BVH_LBVH, **kw)
+    ds = lib.DeviceScene(hs)
+    osc = orc.api.scene_build(12, seed=SEED, flags=abi.RT_SCENE_BVH_LBVH, **kw)
+    su = orc.api.scene_setup(12)
+    cam = orc.api.camera(su)
+    p = orc.make_params(128, 128, 0, 2, list(su.background), seed=SEED)
+    rays = orc.harvest(osc, cam, p, n_paths=20000, max_rays=1 << 15, max_bounce=3)
+    oh, _, ost = orc.trace(osc, rays, seed=SEED, mode=oracle.AABB_TIGHT)
+    gh, work = ds.trace_work(rays, seed=SEED)
+    compare_hits(oh, gh, "1M-triangle mesh, tree built on the device")
+    assert work["inner"] == ost["box_tests"] and work["triangle"] == ost["triangle"]
+    ds.close()
+    hs.close()
+    orc.api.scene_free(osc)
+
+
+def test_builder_call(gpu, orc):
+    def make(api):
+        b = api.builder(seed=3)
+        m = b.lambertian((0.5, 0.5, 0.5))
+        objs = [b.sphere((float(i % 7), float(i // 7), 0.1 * i), 0.3, m) for i in range(40)]
+        objs.append(b.translate(b.rotate_y(b.box6((0, 0, 0), (1, 2, 1), m), 20.0), (3, 3, -4)))
+        return b, b.finish(b.bvh_lbvh(b.list(objs), 0.0, 1.0))
+
+    rays = np.zeros(64, dtype=abi.RAY_DTYPE)
+    rng = np.random.default_rng(5)
+    rays["o"] = rng.uniform(0, 6, (64, 3)) * (1, 1, 0) + (0, 0, -10)
+    rays["d"] = (0, 0, 1)
+    rays["tmin"], rays["tmax"] = 1e-4, np.inf
+    ob, osc = make(orc.api)
+    oh, _, _ = orc.trace(osc, rays, seed=3)
+    gb, handle = make(gpu.host)
+    hs = lib.HostScene(gpu, handle)
+    ds = lib.DeviceScene(hs)
+    gh = ds.trace(rays, seed=3)
+    compare_hits(oh, gh[0] if isinstance(gh, tuple) else gh, "builder scene")
+    assert (oh["prim_id"] != abi.RT_MISS).sum() > 5
+    ds.close()
+    hs.close()
+    orc.api.scene_free(osc)
