@@ -4,7 +4,9 @@ fits one GPU).
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one wavefront batch: `--spp-per-step` samples of every pixel (default 256: 164 M path slots, 38 GB) (generate, then up to 50 bounces of
+A step is one wavefront batch: `--spp-per-step` samples of every pixel (default: 1024, or what fits 672 Mi path slots on larger images;
+final scene: 671 M path slots, 156 GB of the 288 GB; the batch is large because every bounce's launch lasts at least as long as its
+longest ray, however few rays are left) (generate, then up to 50 bounces of
 extend + shade, then accumulate) rendered by every rank into its device-resident accumulation buffer; scene
 tables, path state and image never leave HBM inside the timed region. With N > 1 (one process per GPU,
 torch.distributed over RCCL) every rank renders its own sample range of every pixel (weak scaling: per-GPU
@@ -51,7 +53,7 @@ WORKLOADS = {
 
 
 def scene_kwargs(wl, bvh="reference"):
-    kw = {"flags": abi.RT_SCENE_BVH_WIDEST_AXIS} if bvh == "widest" else {}
+    kw = {"flags": {"widest": abi.RT_SCENE_BVH_WIDEST_AXIS, "lbvh": abi.RT_SCENE_BVH_LBVH}[bvh]} if bvh != "reference" else {}
     if wl["scene"] in (6, 9):
         kw["image"] = assets.earthmap()
     if "n_triangles" in wl:
@@ -100,9 +102,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="final", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp-per-step", type=int, default=256)
-    ap.add_argument("--bvh", default="reference", choices=["reference", "widest"],
-                    help="BVHNode split axis: the reference's random axis (src/bvh.rs:24) or the widest spread of box minima")
+    ap.add_argument("--spp-per-step", type=int, default=0, help="samples of every pixel per step and GPU (default: 1024, fewer on images above 0.69 Mpixel)")
+    ap.add_argument("--bvh", default="reference", choices=["reference", "widest", "lbvh"],
+                    help="BVHNode::new as in the reference (random split axis, src/bvh.rs:24), with the widest-spread axis, "
+                         "or replaced by the linear BVH built on the GPU (rt_bvh_build)")
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the CPU baseline run (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=8, help="the reference's own thread count (src/main.rs:189)")
     args = ap.parse_args()
@@ -128,11 +131,14 @@ def main():
 
     wl = WORKLOADS[args.workload]
     L = lib.get()
+    t_build = time.time()
     hs = lib.HostScene.build(wl["scene"], **scene_kwargs(wl, args.bvh))
+    t_build = time.time() - t_build
     ds = lib.DeviceScene(hs)
     su = L.host.scene_setup(wl["scene"])
     cam = L.host.camera(su)
-    W, H, S = wl["width"], wl["height"], args.spp_per_step
+    W, H = wl["width"], wl["height"]
+    S = args.spp_per_step or max(1, min(1024, (672 << 20) // (W * H)))
     bg = list(su.background)
     accum = torch.zeros(H, W, 3, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -188,7 +194,7 @@ def main():
             "metric": "path samples/s", "value": samples_total / elapsed, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, not a measurement)",
-            "config": {"workload": wl["name"], "width": W, "height": H, "spp_per_step_per_gpu": S, "max_depth": 50, "bvh": args.bvh,
+            "config": {"workload": wl["name"], "width": W, "height": H, "spp_per_step_per_gpu": S, "max_depth": 50, "bvh": args.bvh, "scene_build_s": round(t_build, 3),
                        "sharding": "sample ranges per rank, one RCCL all-reduce of the f32 accumulation buffer"},
             "mrays_per_s": rays * world / elapsed / 1e6 if world == 1 else None,
             "rays_per_sample": rays / (W * H * S * args.steps),

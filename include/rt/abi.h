@@ -163,7 +163,7 @@ typedef struct RtRenderParams {
     uint32_t sample_begin, sample_end;   /* samples [begin, end) of every pixel (src/main.rs:205) */
     uint32_t max_depth;              /* src/main.rs:49 */
     uint32_t samples_per_batch;      /* samples of every pixel traced per wavefront batch; 0 = as many as fit
-                                        160 Mi path slots or a third of the free device memory (232 bytes per slot) */
+                                        640 Mi path slots or half of the free device memory (232 bytes per slot) */
     uint64_t seed;
     double background[3];            /* src/main.rs:62-162 */
 } RtRenderParams;

@@ -18,7 +18,7 @@ using rtd::DevScene;
 using rtd::PathState;
 using rtd::RenderConst;
 
-constexpr uint64_t kDefaultSlotTarget = 160u << 20;  // path slots per wavefront batch when the caller does not say (37 GiB)
+constexpr uint64_t kDefaultSlotTarget = 640ull << 20;  // path slots per wavefront batch when the caller does not say (145 GiB)
 constexpr uint64_t kBytesPerSlot = 2 * sizeof(rtd::RayRec) + sizeof(rtd::HitSlot) + 3 * sizeof(double);
 constexpr int kWorkWords = 10;                      // entries + 9 kinds
 
@@ -225,12 +225,12 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     if (total == 0) return RT_OK;
     uint32_t spb = p->samples_per_batch;
     if (spb == 0) {
-        // Large batches amortise the late bounces, whose launches run at a latency floor however few rays are
-        // left: as many slots as a third of the free device memory holds, up to the default target.
+        // Large batches amortise the late bounces, whose launches take as long as their longest ray however few rays
+        // are left: as many slots as half of the free device memory holds, up to the default target.
         uint64_t target = kDefaultSlotTarget;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            target = std::min<uint64_t>(target, (free_b + s->ws.cap_slots * kBytesPerSlot) / 3 / kBytesPerSlot);
+            target = std::min<uint64_t>(target, (free_b + s->ws.cap_slots * kBytesPerSlot) / 2 / kBytesPerSlot);
         spb = (uint32_t)std::max<uint64_t>(1, target / npix);
     }
     spb = std::min(spb, total);

@@ -32,7 +32,8 @@ def parse_args(argv=None):
     ap.add_argument("--spp-per-batch", type=int, default=0, help="samples of every pixel per wavefront batch (default: sized to the GPU's memory)")
     ap.add_argument("--max-depth", type=int, default=50, help="src/main.rs:49")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
-    ap.add_argument("--bvh", default="reference", choices=["reference", "widest"], help="BVHNode split axis: random (src/bvh.rs:24) or widest spread")
+    ap.add_argument("--bvh", default="reference", choices=["reference", "widest", "lbvh"],
+                    help="BVHNode::new as in the reference (random split axis, src/bvh.rs:24), with the widest-spread axis, or replaced by the linear BVH built on the GPU")
     ap.add_argument("--shutter-bvh", action="store_true", help="random_scene: build the BVH over the shutter interval instead of (0, 0.1) (src/main.rs:315)")
     ap.add_argument("--triangles", type=int, default=1_000_000, help="scene 12: number of synthetic triangles")
     ap.add_argument("--boxes-per-side", type=int, default=0, help="final_scene ground grid (src/main.rs:591)")
@@ -86,7 +87,8 @@ def main(argv=None):
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    flags = (abi.RT_SCENE_BVH_WIDEST_AXIS if args.bvh == "widest" else 0) | (abi.RT_SCENE_BVH_SHUTTER_TIMES if args.shutter_bvh else 0)
+    flags = {"reference": 0, "widest": abi.RT_SCENE_BVH_WIDEST_AXIS, "lbvh": abi.RT_SCENE_BVH_LBVH}[args.bvh]
+    flags |= abi.RT_SCENE_BVH_SHUTTER_TIMES if args.shutter_bvh else 0
     kw = dict(seed=args.seed, flags=flags, boxes_per_side=args.boxes_per_side)
     if args.scene in (6, 9):
         kw["image"] = assets.earthmap()
