@@ -1,0 +1,14 @@
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+for w in weekend cornell smoke; do
+  timeout -k 10 200 python bench.py --workload $w --steps 3 --warmup 1 --cpu-spp 0 > gpurun_out/w_$w.json 2> gpurun_out/w_$w.err || exit 1
+  echo "$w done"
+done
+timeout -k 10 250 python bench.py --workload mesh --bvh lbvh --steps 2 --warmup 1 --cpu-spp 0 > gpurun_out/w_mesh_lbvh.json 2> gpurun_out/w_mesh_lbvh.err || exit 1
+echo "mesh lbvh done"
+timeout -k 10 280 python bench.py --workload mesh --bvh widest --steps 2 --warmup 1 --cpu-spp 0 > gpurun_out/w_mesh_widest.json 2> gpurun_out/w_mesh_widest.err || exit 1
+echo "mesh widest done"
+timeout -k 10 280 python bench.py --workload mesh --bvh reference --spp-per-step 16 --steps 1 --warmup 1 --cpu-spp 0 > gpurun_out/w_mesh_reference.json 2> gpurun_out/w_mesh_reference.err || exit 1
+echo "mesh reference done"
+timeout -k 10 120 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bvh -o bvh -- python3 tools/bvh_build_time.py 10000000 > gpurun_out/bvh_build_time.txt 2>&1 || exit 1
+echo "bvh build done"
