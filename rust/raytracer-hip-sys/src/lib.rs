@@ -60,4 +60,7 @@ extern "C" {
     pub fn rt_render_work(scene: *mut RtScene, cam: *const RtCamera, params: *const RtRenderParams, accum_rgb_dev: *mut f32, stream: *mut c_void, stats: *mut RtRenderStats, work: *mut u64) -> c_int;
     pub fn rt_resolve_u8(accum_rgb: *const f32, width: u32, height: u32, spp: u64, rgb_out: *mut u8) -> c_int;
     pub fn rt_resolve_u8_device(accum_rgb_dev: *const f32, width: u32, height: u32, spp: u64, rgb_out_dev: *mut u8, stream: *mut c_void) -> c_int;
+    /// boxes: n x 6 f64 (min xyz, max xyz); tokens_out: 2 n - 1 records in pre-order (leaf: meta == RT_BVH_TOKEN_LEAF, link = object)
+    pub fn rt_bvh_build(boxes: *const f64, n: u64, tokens_out: *mut RtNode, ms_device: *mut f64) -> c_int;
 }
+pub const RT_BVH_TOKEN_LEAF: u32 = 0xF;
