@@ -77,9 +77,21 @@ def algorithmic_bytes(rays, work):
     return rays * (RAY_IN_BYTES + HIT_OUT_BYTES) + 32 * work["entries"] + sum(ROW_BYTES[k] * work[k] for k in ROW_BYTES)
 
 
-def cpu_baseline(wl, spp, threads):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(wl, spp, threads, more_threads=0):
     """The CPU oracle (oracle/, a C++ restatement of the reference) on the same scene and image size, `spp`
-    samples per pixel, `threads` std::threads splitting columns as src/main.rs:193-195 does."""
+    samples per pixel, `threads` std::threads splitting columns as src/main.rs:193-195 does; when `more_threads`
+    is given, a second run with that many threads (the share of the host's cores this job may use) is reported too."""
     import oracle
     o = oracle.get()
     kw = scene_kwargs(wl)
@@ -87,13 +99,17 @@ def cpu_baseline(wl, spp, threads):
     su = o.api.scene_setup(wl["scene"])
     cam = o.api.camera(su)
     p = o.make_params(wl["width"], wl["height"], 0, spp, list(su.background))
-    _, st, secs = o.render(sc, cam, p, mode=oracle.AABB_REFERENCE, threads=threads)
-    o.api.scene_free(sc)
     n = wl["width"] * wl["height"] * spp
-    return {"value": n / secs, "unit": "path samples/s", "cores": threads, "kind": "port",
-            "sample": "%s, %d spp (%d path samples, %.1f s), reference AABB test, %d threads over image columns"
-                      % (wl["name"], spp, n, secs, threads),
-            "rays_per_s": st["rays"] / secs}
+    _, st, secs = o.render(sc, cam, p, mode=oracle.AABB_REFERENCE, threads=threads)
+    out = {"value": n / secs, "unit": "path samples/s", "cores": threads, "kind": "port",
+           "sample": "%s, %d spp (%d path samples, %.1f s), reference AABB test, %d threads over image columns"
+                     % (wl["name"], spp, n, secs, threads),
+           "rays_per_s": st["rays"] / secs, "cpu_model": cpu_model()}
+    if more_threads > threads:
+        _, _, secs2 = o.render(sc, cam, p, mode=oracle.AABB_REFERENCE, threads=more_threads)
+        out["more_threads"] = {"value": n / secs2, "cores": more_threads, "seconds": round(secs2, 1)}
+    o.api.scene_free(sc)
+    return out
 
 
 def main():
@@ -108,6 +124,8 @@ def main():
                          "or replaced by the linear BVH built on the GPU (rt_bvh_build)")
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the CPU baseline run (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=8, help="the reference's own thread count (src/main.rs:189)")
+    ap.add_argument("--cpu-more-threads", type=int, default=16,
+                    help="a second CPU run with this many threads (the CPU share of a one-GPU job on the box; 0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,7 +228,7 @@ def main():
                                   if table_bytes <= 144 * 1024 else "scene tables are read from HBM / L2")},
         }
         if args.cpu_spp > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_spp, args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_spp, args.cpu_threads, args.cpu_more_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

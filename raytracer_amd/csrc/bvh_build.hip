@@ -1,13 +1,17 @@
 // rt_bvh_build: a binary tree over n bounding boxes, built on the device. It stands in for the host recursion of
 // BVHNode::new (src/bvh.rs:17-98) where that tree need not be reproduced: objects ordered by the Morton code of their
 // box centres (Lauterbach et al. 2009), the binary radix tree over the ordered codes built with one thread per inner
-// node (Karras 2012), boxes united bottom-up (src/aabb.rs:33-50), and the tree written out in pre-order.
+// node (Karras 2012), and the tree written out in pre-order. The box of a node is the union (src/aabb.rs:33-50) of the
+// boxes of a contiguous range of sorted leaves, so no thread waits for another: unions over every 64-leaf block from
+// its start and to its end, a sparse table over whole blocks, and each node combines at most four of those. min and max
+// are exact and associative: the result is the box that uniting the children's boxes gives, bit for bit.
 //
 // Everything that decides the shape of the tree is exact: centres and their quantisation use + - * / in f64 without
 // contraction, the sort is stable, ties between equal codes are broken by sorted position. A CPU builder following the
 // same definition therefore gives the same tokens bit for bit.
 //
-// Device memory per object: 48 B box in, 2 x 12 B sort keys and values, 28 B tree links, 48 B node box, 64 B tokens.
+// Device memory per object: 48 B box in, 2 x 12 B sort keys and values, 20 B tree links, 2 x 48 B block unions, 64 B tokens,
+// and 48 B x log2(n / 64) per 64 objects for the table.
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -25,20 +29,21 @@ constexpr int BLOCK = 256;
 constexpr int MAX_DEPTH = 128;           // more than the 96 bits of a key (code, sorted position)
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr uint32_t RIGHT = 0x80000000u;  // in a parent link: the node is its parent's right child
-constexpr uint32_t LEAF = 0x80000000u;   // in a child link: the child is a leaf
+
+constexpr uint32_t RANGE = 64u;          // leaves per block of the range unions: one wave scans a block
 
 struct Tree {
     const uint64_t* code;   // n sorted codes
     const uint32_t* object; // n: object of sorted position
-    uint32_t* child;        // 2 (n - 1): left, right of inner node i (LEAF flag)
     uint32_t* parent_inner; // n - 1 (RIGHT flag); NONE for the root
     uint32_t* parent_leaf;  // n
     uint32_t* first;        // n - 1: first sorted position under inner node i
     uint32_t* last;         // n - 1
     uint32_t* split;        // n - 1: last sorted position of the left subtree
-    uint32_t* visits;       // n - 1, zeroed
-    double* node_box;       // (n - 1) x 6
-    uint32_t n;
+    double* from_start;     // n x 6: union of the leaf boxes from the start of the leaf's block up to the leaf
+    double* to_end;         // n x 6: union from the leaf to the end of its block
+    double* table;          // levels x blocks x 6: table[k][b] = union of blocks b .. b + 2^k - 1 (clipped at the end)
+    uint32_t n, blocks;
 };
 
 __device__ inline uint64_t spread21(uint64_t v) {  // bit i -> bit 3 i
@@ -159,55 +164,80 @@ __global__ __launch_bounds__(BLOCK) void k_radix_tree(Tree t) {
     t.first[i] = (uint32_t)lo;
     t.last[i] = (uint32_t)hi;
     t.split[i] = (uint32_t)gamma;
-    if (lo == gamma) { t.child[2 * i] = (uint32_t)gamma | LEAF; t.parent_leaf[gamma] = (uint32_t)i; }
-    else { t.child[2 * i] = (uint32_t)gamma; t.parent_inner[gamma] = (uint32_t)i; }
-    if (hi == gamma + 1) { t.child[2 * i + 1] = (uint32_t)(gamma + 1) | LEAF; t.parent_leaf[gamma + 1] = (uint32_t)i | RIGHT; }
-    else { t.child[2 * i + 1] = (uint32_t)(gamma + 1); t.parent_inner[gamma + 1] = (uint32_t)i | RIGHT; }
+    // the left child is leaf gamma when the range starts there, else inner node gamma; likewise gamma + 1 on the right
+    if (lo == gamma) t.parent_leaf[gamma] = (uint32_t)i; else t.parent_inner[gamma] = (uint32_t)i;
+    if (hi == gamma + 1) t.parent_leaf[gamma + 1] = (uint32_t)i | RIGHT; else t.parent_inner[gamma + 1] = (uint32_t)i | RIGHT;
     if (i == 0) t.parent_inner[0] = NONE;
 }
 
-// One thread per leaf climbs towards the root; the second thread to reach a node unites the box it carries with the
-// sibling's, which the first thread stored before it left (fence, then the counter).
-__global__ __launch_bounds__(BLOCK) void k_unite_boxes(Tree t, const double* __restrict__ boxes) {
-    const uint64_t leaf = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (leaf >= t.n) return;
-    double mine[6];
-    {
-        const uint64_t o = t.object[leaf];
-        for (int k = 0; k < 6; ++k) mine[k] = boxes[6 * o + k];
+struct Box6d {
+    double v[6];  // min x y z, max x y z
+};
+__device__ inline Box6d empty_box() { return Box6d{{INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}}; }
+__device__ inline Box6d unite(Box6d a, const Box6d& b) {
+    for (int k = 0; k < 3; ++k) { a.v[k] = fmin(a.v[k], b.v[k]); a.v[3 + k] = fmax(a.v[3 + k], b.v[3 + k]); }
+    return a;
+}
+__device__ inline Box6d load_box(const double* __restrict__ p, uint64_t i) {
+    Box6d b;
+    for (int k = 0; k < 6; ++k) b.v[k] = p[6 * i + k];
+    return b;
+}
+__device__ inline void store_box(double* __restrict__ p, uint64_t i, const Box6d& b) {
+    for (int k = 0; k < 6; ++k) p[6 * i + k] = b.v[k];
+}
+
+// One wave per block of 64 sorted leaves: the unions from the block's start up to each leaf and from each leaf to the
+// block's end (two wave scans), and the union of the whole block as level 0 of the table.
+__global__ __launch_bounds__(BLOCK) void k_block_unions(Tree t, const double* __restrict__ boxes) {
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool live = i < t.n;
+    Box6d fwd = live ? load_box(boxes, t.object[i]) : empty_box();
+    Box6d bwd = fwd;
+    for (uint32_t o = 1; o < RANGE; o <<= 1) {
+        Box6d a, b;
+        for (int k = 0; k < 6; ++k) { a.v[k] = __shfl_up(fwd.v[k], o, 64); b.v[k] = __shfl_down(bwd.v[k], o, 64); }
+        if (lane >= o) fwd = unite(fwd, a);
+        if (lane + o < RANGE) bwd = unite(bwd, b);
     }
-    uint32_t up = t.parent_leaf[leaf];
-    bool carried_is_leaf = true;
-    uint64_t carried = leaf;
-    for (int depth = 0; depth < MAX_DEPTH; ++depth) {
-        const uint32_t node = up & ~RIGHT;
-        if (!carried_is_leaf) {
-            for (int k = 0; k < 6; ++k) t.node_box[6 * carried + k] = mine[k];
-        }
-        __threadfence();
-        if (atomicAdd(&t.visits[node], 1u) == 0u) return;  // the sibling subtree is not finished: its thread goes on
-        __threadfence();
-        const uint32_t other = t.child[2 * (uint64_t)node + ((up & RIGHT) ? 0 : 1)];
-        double theirs[6];
-        if (other & LEAF) {
-            const uint64_t o = t.object[other & ~LEAF];
-            for (int k = 0; k < 6; ++k) theirs[k] = boxes[6 * o + k];
-        } else {
-            const double* src = t.node_box + 6 * (uint64_t)other;
-            for (int k = 0; k < 6; ++k) theirs[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        for (int k = 0; k < 3; ++k) {
-            mine[k] = fmin(mine[k], theirs[k]);
-            mine[3 + k] = fmax(mine[3 + k], theirs[3 + k]);
-        }
-        carried = node;
-        carried_is_leaf = false;
-        up = t.parent_inner[node];
-        if (up == NONE) {
-            for (int k = 0; k < 6; ++k) t.node_box[6 * (uint64_t)node + k] = mine[k];
-            return;
-        }
+    if (live) {
+        store_box(t.from_start, i, fwd);
+        store_box(t.to_end, i, bwd);
+        if (lane == 0u) store_box(t.table, i / RANGE, bwd);
     }
+}
+
+// level k of the table from level k - 1
+__global__ __launch_bounds__(BLOCK) void k_table_level(Tree t, uint32_t k) {
+    const uint64_t b = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= t.blocks) return;
+    const double* below = t.table + 6ull * t.blocks * (k - 1);
+    Box6d x = load_box(below, b);
+    const uint64_t right = b + (1ull << (k - 1));
+    if (right < t.blocks) x = unite(x, load_box(below, right));
+    store_box(t.table + 6ull * t.blocks * k, b, x);
+}
+
+// the union of the leaf boxes of sorted positions [l, r], l < r
+__device__ inline Box6d range_box(const Tree& t, const double* __restrict__ boxes, uint32_t l, uint32_t r) {
+    const uint32_t bl = l / RANGE, br = r / RANGE;
+    if (bl == br) {
+        if (l % RANGE == 0u) return load_box(t.from_start, r);
+        if (r % RANGE == RANGE - 1u || r == t.n - 1u) return load_box(t.to_end, l);
+        Box6d x = load_box(boxes, t.object[l]);
+        for (uint32_t i = l + 1u; i <= r; ++i) x = unite(x, load_box(boxes, t.object[i]));
+        return x;
+    }
+    Box6d x = unite(load_box(t.to_end, l), load_box(t.from_start, r));
+    if (br > bl + 1u) {  // whole blocks bl + 1 .. br - 1: two overlapping table entries
+        const uint32_t len = br - bl - 1u;
+        const uint32_t k = 31u - (uint32_t)__clz((int)len);
+        const double* level = t.table + 6ull * t.blocks * k;
+        x = unite(x, load_box(level, bl + 1u));
+        x = unite(x, load_box(level, br - (1u << k)));
+    }
+    return x;
 }
 
 __device__ inline float f32_down(double v) {
@@ -223,7 +253,7 @@ __device__ inline float f32_up(double v) {
 
 // One thread per node. Pre-order position: the root is token 0; a left child follows its parent; a right child
 // follows the 2 L - 1 tokens of the left subtree (L leaves).
-__global__ __launch_bounds__(BLOCK) void k_tokens(Tree t, RtNode* __restrict__ tokens) {
+__global__ __launch_bounds__(BLOCK) void k_tokens(Tree t, const double* __restrict__ boxes, RtNode* __restrict__ tokens) {
     const uint64_t id = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t n = t.n;
     if (id >= 2ull * n - 1) return;
@@ -239,8 +269,8 @@ __global__ __launch_bounds__(BLOCK) void k_tokens(Tree t, RtNode* __restrict__ t
     }
     RtNode out;
     if (inner) {
-        double b[6];
-        for (int k = 0; k < 6; ++k) b[k] = t.node_box[6 * self + k];
+        const Box6d box = range_box(t, boxes, t.first[self], t.last[self]);
+        const double* b = box.v;
         const bool flat = b[0] == b[3] || b[1] == b[4] || b[2] == b[5];
         for (int a = 0; a < 3; ++a) {
             out.lo[a] = flat ? INFINITY : f32_down(b[a]);
@@ -299,23 +329,26 @@ extern "C" int rt_bvh_build(const double* boxes, uint64_t n64, RtNode* tokens_ou
     const uint32_t n = (uint32_t)n64;
     const uint32_t inner = n - 1;
     DeviceBuffers mem;
-    double *d_boxes, *d_partial, *d_bounds, *d_node_box;
+    double *d_boxes, *d_partial, *d_bounds, *d_from_start, *d_to_end, *d_table;
     uint64_t *d_code_in, *d_code;
-    uint32_t *d_obj_in, *d_obj, *d_child, *d_parent_inner, *d_parent_leaf, *d_first, *d_last, *d_split, *d_visits, *d_bad;
+    uint32_t *d_obj_in, *d_obj, *d_parent_inner, *d_parent_leaf, *d_first, *d_last, *d_split, *d_bad;
     RtNode* d_tokens;
     const uint32_t reduce_blocks = (uint32_t)std::min<uint64_t>(1024, (n64 + BLOCK - 1) / BLOCK);
+    const uint32_t blocks = (n + RANGE - 1u) / RANGE;
+    uint32_t levels = 1;
+    while ((2u << (levels - 1)) <= blocks) ++levels;  // levels - 1 = floor(log2(blocks))
     BVH_TRY(mem.get(&d_boxes, 6ull * n));
     BVH_TRY(mem.get(&d_partial, 6ull * reduce_blocks + 6 + 2));
     BVH_TRY(mem.get(&d_code_in, n));
     BVH_TRY(mem.get(&d_code, n));
     BVH_TRY(mem.get(&d_obj_in, n));
     BVH_TRY(mem.get(&d_obj, n));
-    BVH_TRY(mem.get(&d_child, 2ull * inner));
     BVH_TRY(mem.get(&d_parent_inner, inner));
     BVH_TRY(mem.get(&d_parent_leaf, n));
     BVH_TRY(mem.get(&d_first, 3ull * inner));
-    BVH_TRY(mem.get(&d_visits, inner));
-    BVH_TRY(mem.get(&d_node_box, 6ull * inner));
+    BVH_TRY(mem.get(&d_from_start, 6ull * n));
+    BVH_TRY(mem.get(&d_to_end, 6ull * n));
+    BVH_TRY(mem.get(&d_table, 6ull * blocks * levels));
     BVH_TRY(mem.get(&d_tokens, 2ull * n - 1));
     d_bounds = d_partial + 6ull * reduce_blocks;
     d_bad = (uint32_t*)(d_bounds + 6);
@@ -329,7 +362,6 @@ extern "C" int rt_bvh_build(const double* boxes, uint64_t n64, RtNode* tokens_ou
     BVH_TRY(hipEventCreate(&mem.e1));
 
     BVH_TRY(hipMemcpy(d_boxes, boxes, 6ull * n * sizeof(double), hipMemcpyHostToDevice));
-    BVH_TRY(hipMemsetAsync(d_visits, 0, (uint64_t)inner * sizeof(uint32_t), nullptr));
     BVH_TRY(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), nullptr));
     BVH_TRY(hipEventRecord(mem.e0, nullptr));
     const uint32_t per_leaf = (n + BLOCK - 1) / BLOCK, per_inner = (inner + BLOCK - 1) / BLOCK;
@@ -339,10 +371,12 @@ extern "C" int rt_bvh_build(const double* boxes, uint64_t n64, RtNode* tokens_ou
     hipLaunchKernelGGL(k_morton, dim3(per_leaf), dim3(BLOCK), 0, nullptr, d_boxes, n, d_bounds, d_code_in, d_obj_in);
     BVH_TRY(hipGetLastError());
     BVH_TRY(rocprim::radix_sort_pairs(d_sort, sort_bytes, d_code_in, d_code, d_obj_in, d_obj, (size_t)n, 0u, 63u, (hipStream_t) nullptr));
-    Tree t{d_code, d_obj, d_child, d_parent_inner, d_parent_leaf, d_first, d_last, d_split, d_visits, d_node_box, n};
+    Tree t{d_code, d_obj, d_parent_inner, d_parent_leaf, d_first, d_last, d_split, d_from_start, d_to_end, d_table, n, blocks};
     hipLaunchKernelGGL(k_radix_tree, dim3(per_inner), dim3(BLOCK), 0, nullptr, t);
-    hipLaunchKernelGGL(k_unite_boxes, dim3(per_leaf), dim3(BLOCK), 0, nullptr, t, d_boxes);
-    hipLaunchKernelGGL(k_tokens, dim3(per_node), dim3(BLOCK), 0, nullptr, t, d_tokens);
+    hipLaunchKernelGGL(k_block_unions, dim3(per_leaf), dim3(BLOCK), 0, nullptr, t, d_boxes);
+    for (uint32_t k = 1; k < levels; ++k)
+        hipLaunchKernelGGL(k_table_level, dim3((blocks + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, nullptr, t, k);
+    hipLaunchKernelGGL(k_tokens, dim3(per_node), dim3(BLOCK), 0, nullptr, t, d_boxes, d_tokens);
     BVH_TRY(hipGetLastError());
     BVH_TRY(hipEventRecord(mem.e1, nullptr));
     uint32_t bad = 0;
