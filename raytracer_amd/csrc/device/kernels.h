@@ -358,16 +358,43 @@ __global__ void __launch_bounds__(TRACE_BLOCK, 2) k_trace(DevScene S0, LdsPlan p
 
 // ---- generate: camera rays of one batch (src/main.rs:206-209, src/camera.rs:61-71) ---------
 __global__ void __launch_bounds__(BLOCK) k_generate(RenderConst C, PathState P) {
+    // A lane's record is 96 bytes, so lanes storing their own records would touch 48 cache lines per store
+    // instruction; the wave lays its 64 records out in LDS instead and writes the 6 KiB out in address order.
+    __shared__ uint4 s_rec[BLOCK / 64][64 * 6];
     const uint32_t stride = gridDim.x * BLOCK;
-    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < C.n_slots; slot += stride) {
-        const uint32_t pix = slot % C.npix;
-        const uint32_t sample = C.sample0 + slot / C.npix;
-        const uint32_t x = pix % C.width, y = pix / C.width;
-        V3 o, d;
-        double tm;
-        camera_ray(C.cam, C.seed, C.width, C.height, x, y, pix, sample, o, d, tm);
-        store_ray(P.rec[0] + slot, o, d, tm, slot, v3(1.0, 1.0, 1.0));
-        P.lr[slot] = 0.0; P.lg[slot] = 0.0; P.lb[slot] = 0.0;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint4* mine = s_rec[threadIdx.x >> 6];
+    const uint32_t n_round = (C.n_slots + 63u) & ~63u;  // whole waves, so that every lane takes part in the copy
+    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n_round; slot += stride) {
+        if (slot < C.n_slots) {
+            const uint32_t pix = slot % C.npix;
+            const uint32_t sample = C.sample0 + slot / C.npix;
+            const uint32_t x = pix % C.width, y = pix / C.width;
+            V3 o, d;
+            double tm;
+            camera_ray(C.cam, C.seed, C.width, C.height, x, y, pix, sample, o, d, tm);
+            double2* r = reinterpret_cast<double2*>(mine + lane * 6u);
+            r[0] = make_double2(o.x, o.y);
+            r[1] = make_double2(o.z, d.x);
+            r[2] = make_double2(d.y, d.z);
+            uint4 e;
+            e.x = (uint32_t)__double2loint(tm); e.y = (uint32_t)__double2hiint(tm); e.z = slot; e.w = 0u;
+            mine[lane * 6u + 3u] = e;
+            r[4] = make_double2(1.0, 1.0);
+            r[5] = make_double2(1.0, 0.0);
+            P.lr[slot] = 0.0; P.lg[slot] = 0.0; P.lb[slot] = 0.0;
+        }
+        // lanes read what other lanes of the wave wrote: the wave runs in lockstep and LDS keeps its order; the fence
+        // and the scheduling barrier keep the compiler from moving accesses across this point
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // the records of this wave's 64 slots are contiguous: slot - lane is the first
+        const uint32_t first = slot - lane;
+        const uint32_t n_chunks = (C.n_slots - first < 64u ? C.n_slots - first : 64u) * 6u;
+        uint4* out = reinterpret_cast<uint4*>(P.rec[0] + first);
+        for (uint32_t q = lane; q < n_chunks; q += 64u) out[q] = mine[q];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
