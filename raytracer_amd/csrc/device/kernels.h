@@ -523,7 +523,10 @@ RT_D bool shade_one(const SC& S, const RenderConst& C, const PathState& P, uint3
 struct SurvivorOut {
     RayRec* next;
     uint32_t* next_count;
+    uint4* stage;  // 64 records of LDS owned by this wave
     uint32_t chunk, o_next, o_end, survivors;
+    // A lane storing its own 96-byte record makes the wave touch 48 cache lines per store instruction, each only in
+    // part; the survivors are laid out in LDS in output order instead and copied out in address order.
     RT_D void emit(bool alive, uint32_t lane, V3 no, V3 nd, double tm, uint32_t slot, V3 T) {
         const unsigned long long mask = __ballot(alive);
         if (!mask) return;
@@ -537,7 +540,18 @@ struct SurvivorOut {
             o_end = base + want;
         }
         const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (alive) store_ray(next + (rank < avail ? o_next + rank : base + (rank - avail)), no, nd, tm, slot, T);
+        if (alive) store_ray(reinterpret_cast<RayRec*>(stage + rank * 6u), no, nd, tm, slot, T);
+        // lanes read what other lanes of the wave wrote: the wave runs in lockstep and LDS keeps its order; the fence
+        // and the scheduling barrier keep the compiler from moving accesses across this point
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t q = lane; q < cnt * 6u; q += 64u) {
+            const uint32_t r = q / 6u, piece = q - r * 6u;
+            const uint32_t dest = r < avail ? o_next + r : base + (r - avail);
+            reinterpret_cast<uint4*>(next + dest)[piece] = stage[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         o_next = avail < cnt ? base + (cnt - avail) : o_next + cnt;
         survivors += cnt;
     }
@@ -559,7 +573,9 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
     }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total_waves = gridDim.x * (SHADE_BLOCK / 64u);
+    __shared__ uint4 s_stage[SHADE_BLOCK / 64][64 * 6];
     SurvivorOut out;
+    out.stage = s_stage[threadIdx.x >> 6];
     out.next = P.rec[cur ^ 1u];
     out.next_count = counts + (cur ^ 1u);
     out.chunk = n / total_waves >= OUT_MIN_CHUNKS * OUT_CHUNK ? OUT_CHUNK : 0u;
@@ -682,6 +698,8 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
 
 // LDS bytes the sorting variant of the shade kernel declares for itself (bins, permutations, chunk counters)
 constexpr uint32_t SHADE_SORT_LDS = 2u * SORT_BINS * 4u + 2u * SORT_WINDOW * 2u + 16u;
+// LDS bytes both variants declare for laying out the survivors' records
+constexpr uint32_t SHADE_STAGE_LDS = (SHADE_BLOCK / 64u) * 64u * 6u * 16u;
 
 template <bool LDS, bool SORT>
 __global__ void __launch_bounds__(SHADE_BLOCK, RT_SHADE_WAVES) k_shade(DevScene S0, LdsPlan plan, RenderConst C, PathState P,

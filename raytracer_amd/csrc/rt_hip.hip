@@ -386,8 +386,9 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
                 }
                 s->shade_sort = classes >= 6;
             }
-            const uint32_t kSortBudget = kBudget - ((rtd::SHADE_SORT_LDS + 1023u) & ~1023u);
-            const uint32_t kShadeBudget = s->shade_sort ? kSortBudget : kBudget;
+            const uint32_t kPlainBudget = kBudget - rtd::SHADE_STAGE_LDS;
+            const uint32_t kSortBudget = kPlainBudget - ((rtd::SHADE_SORT_LDS + 1023u) & ~1023u);
+            const uint32_t kShadeBudget = s->shade_sort ? kSortBudget : kPlainBudget;
             auto pad = [](uint64_t bytes) { return (bytes + 15u) & ~15ull; };
             const uint64_t prims = pad(d->n_spheres * sizeof(RtSphere)) + pad(d->n_msphere * sizeof(RtMovingSphere)) + pad(d->n_rects * sizeof(RtRect)) +
                                    pad(d->n_boxes * sizeof(RtBox6)) + pad(d->n_triangles * sizeof(RtTriangle)) + pad(d->n_xforms * sizeof(RtXform)) +
@@ -452,13 +453,13 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
             RT_BIG_LDS_P(0); RT_BIG_LDS_P(1); RT_BIG_LDS_P(3); RT_BIG_LDS_P(4); RT_BIG_LDS_P(5); RT_BIG_LDS_P(7);
 #undef RT_BIG_LDS_P
 #undef RT_BIG_LDS
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlainBudget);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortBudget);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlainBudget);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortBudget);
             (void)hipGetLastError();  // a refused attribute must not surface as the error of a later launch
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
