@@ -37,6 +37,7 @@ struct PathState {
 // slot value of a padding record: the shade kernel reserves output records in chunks and pads what a wave did
 // not use; extend and shade skip such records
 constexpr uint32_t DEAD_SLOT = 0xFFFFFFFFu;
+constexpr uint32_t DEAD_REF = 0xFFFFFFFEu;   // HitSlot::ref of a padding record (no entry has kind 14)
 
 // 16-byte loads/stores of a record (global_load_dwordx4 / global_store_dwordx4)
 RT_D void load_ray64(const RayRec* r, V3& o, V3& d, double& tm, uint32_t& slot) {
@@ -261,6 +262,8 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
                     if (io.fetch(index, ray)) {
                         w.init(S, ray.o, ray.d, ray.tm, ray.tmin, ray.tmax);
                         busy = true;
+                    } else {
+                        io.skip(index);
                     }
                 }
                 c_next = more ? base + (room - avail) : c_next + take;
@@ -306,6 +309,7 @@ struct TraceIO {
         r.rs.r = q;
         return true;
     }
+    RT_D void skip(uint32_t) const {}
     template <class SC>
     RT_D void store(const SC& S, uint32_t i, const Ray& r, const Cand& best) const {
         V3 o, d;
@@ -424,6 +428,9 @@ struct ExtendIO {
         r.key.seed = seed; r.key.pixel = slot % npix; r.key.sample = sample0 + slot / npix; r.key.bounce = bounce;
         return slot != DEAD_SLOT;
     }
+    // a padding record: marked in the hit array, so that the shade kernel's sorting pass can tell without touching
+    // the record
+    RT_D void skip(uint32_t i) const { hits[i].ref = DEAD_REF; }
     template <class SC>
     RT_D void store(const SC&, uint32_t i, const Ray&, const Cand& best) const {
         uint4 h;
@@ -599,7 +606,10 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
         for (uint32_t k = 0; k < SORT_ROUNDS; ++k) {
             const uint32_t i = base + k * SHADE_BLOCK + threadIdx.x;
             uint32_t key = SORT_BINS - 1u;  // no ray: beyond n, or a padding record
-            if (i < n && recs[i].slot != DEAD_SLOT) key = shade_key(S, P.hit[i].ref);
+            if (i < n) {
+                const uint32_t ref = P.hit[i].ref;
+                if (ref != DEAD_REF) key = shade_key(S, ref);
+            }
             keys[k] = key;
             ranks[k] = atomicAdd(&hist[key], 1u);
         }
