@@ -480,7 +480,7 @@ RT_D void add_radiance(const PathState& P, uint32_t slot, V3 add) {
 // kind. The last bin is reserved for "no ray".
 constexpr uint32_t SORT_BINS = 192u;                      // 3 per lane of the wave that scans them
 #ifndef RT_SORT_ROUNDS
-#define RT_SORT_ROUNDS 8
+#define RT_SORT_ROUNDS 12  // measured on the final scene, shade ms per 1024-spp step: 2 -> 271, 4 -> 201, 8 -> 175, 12 -> 168, 16 -> 168, 24 -> 167
 #endif
 constexpr uint32_t SORT_ROUNDS = RT_SORT_ROUNDS;                      // records per thread and window
 constexpr uint32_t SORT_WINDOW = SHADE_BLOCK * SORT_ROUNDS;

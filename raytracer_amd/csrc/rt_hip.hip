@@ -373,8 +373,9 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
             const uint32_t kBudget = 144u * 1024u;  // of the 160 KiB of a CU; one workgroup per CU
             // the shade kernel's own LDS arrays (sorting windows, when built with them) come out of its share
             // Sorting the rays of a window by what shading them involves pays when a scene has many kinds of material
-            // (measured: +12 % shade on the final scene with 7, -20 % on Cornell with 2); the sorting variant's own
-            // LDS arrays come out of the kernel's share.
+            // (measured, shade ms per 1024-spp step sorted / unsorted: Weekend with 4 kinds 113 / 108, Cornell with 2
+            // 118 / 109, Cornell smoke with 3 142 / 147, final scene with 7 168 / 190); the sorting variant's own LDS
+            // arrays come out of the kernel's share.
             {
                 bool seen[5][4] = {};
                 uint32_t classes = 0;
@@ -384,7 +385,10 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
                     const uint32_t tk = textured ? d->textures[m.tex].kind : 0u;
                     if (!seen[m.kind][tk]) { seen[m.kind][tk] = true; ++classes; }
                 }
-                s->shade_sort = classes >= 6;
+#ifndef RT_SORT_MIN_CLASSES
+#define RT_SORT_MIN_CLASSES 6
+#endif
+                s->shade_sort = classes >= RT_SORT_MIN_CLASSES;
             }
             const uint32_t kPlainBudget = kBudget - rtd::SHADE_STAGE_LDS;
             const uint32_t kSortBudget = kPlainBudget - ((rtd::SHADE_SORT_LDS + 1023u) & ~1023u);
