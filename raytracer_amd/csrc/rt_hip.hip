@@ -374,7 +374,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
             // the shade kernel's own LDS arrays (sorting windows, when built with them) come out of its share
             // Sorting the rays of a window by what shading them involves pays when a scene has many kinds of material
             // (measured, shade ms per 1024-spp step sorted / unsorted: Weekend with 4 kinds 113 / 108, Cornell with 2
-            // 118 / 109, Cornell smoke with 3 142 / 147, final scene with 7 168 / 190); the sorting variant's own LDS
+            // 118 / 109, Cornell smoke with 3 142 / 147; final scene with 7: 12 % less sorted); the sorting variant's own LDS
             // arrays come out of the kernel's share.
             {
                 bool seen[5][4] = {};
