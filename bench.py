@@ -53,11 +53,14 @@ WORKLOADS = {
 
 
 def scene_kwargs(wl, bvh="reference"):
+    """Options of the scene builder; a workload dict may carry boxes_per_side (--boxes-per-side)."""
     kw = {"flags": {"widest": abi.RT_SCENE_BVH_WIDEST_AXIS, "lbvh": abi.RT_SCENE_BVH_LBVH}[bvh]} if bvh != "reference" else {}
     if wl["scene"] in (6, 9):
         kw["image"] = assets.earthmap()
     if "n_triangles" in wl:
         kw["n_triangles"] = wl["n_triangles"]
+    if wl.get("boxes_per_side"):
+        kw["boxes_per_side"] = wl["boxes_per_side"]
     return kw
 
 
@@ -122,6 +125,8 @@ def main():
     ap.add_argument("--bvh", default="reference", choices=["reference", "widest", "lbvh"],
                     help="BVHNode::new as in the reference (random split axis, src/bvh.rs:24), with the widest-spread axis, "
                          "or replaced by the linear BVH built on the GPU (rt_bvh_build)")
+    ap.add_argument("--boxes-per-side", type=int, default=0,
+                    help="final scene only: side of the ground grid of boxes (src/main.rs:591 has 20); larger grids no longer fit LDS")
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the CPU baseline run (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=8, help="the reference's own thread count (src/main.rs:189)")
     ap.add_argument("--cpu-more-threads", type=int, default=16,
@@ -147,7 +152,10 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.boxes_per_side and args.workload == "final":
+        wl["boxes_per_side"] = args.boxes_per_side
+        wl["name"] += " with %d x %d ground boxes" % (args.boxes_per_side, args.boxes_per_side)
     L = lib.get()
     t_build = time.time()
     hs = lib.HostScene.build(wl["scene"], **scene_kwargs(wl, args.bvh))
