@@ -164,7 +164,11 @@ def main():
     su = L.host.scene_setup(wl["scene"])
     cam = L.host.camera(su)
     W, H = wl["width"], wl["height"]
-    S = args.spp_per_step or max(1, min(1024, (672 << 20) // (W * H)))
+    S = args.spp_per_step
+    if not S:
+        # 232 bytes of path state per slot; never more than 60 % of what is free on this GPU
+        free_bytes, _ = torch.cuda.mem_get_info()
+        S = max(1, min(1024, (672 << 20) // (W * H), int(0.6 * free_bytes) // (232 * W * H)))
     bg = list(su.background)
     accum = torch.zeros(H, W, 3, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
