@@ -100,6 +100,7 @@ def cpu_baseline(wl, spp, threads, more_threads=0):
     kw = scene_kwargs(wl)
     sc = o.api.scene_build(wl["scene"], **kw)
     su = o.api.scene_setup(wl["scene"])
+    su.aspect_ratio = wl["width"] / wl["height"]
     cam = o.api.camera(su)
     p = o.make_params(wl["width"], wl["height"], 0, spp, list(su.background))
     n = wl["width"] * wl["height"] * spp
@@ -162,6 +163,7 @@ def main():
     t_build = time.time() - t_build
     ds = lib.DeviceScene(hs)
     su = L.host.scene_setup(wl["scene"])
+    su.aspect_ratio = wl["width"] / wl["height"]  # the camera follows the image (C5: 16:9 at 4K; the others: their nominal ratio)
     cam = L.host.camera(su)
     W, H = wl["width"], wl["height"]
     S = args.spp_per_step

@@ -15,6 +15,7 @@ L = lib.get()
 hs = lib.HostScene.build(wl["scene"], **bench.scene_kwargs(wl, bvh))
 ds = lib.DeviceScene(hs)
 su = L.host.scene_setup(wl["scene"])
+su.aspect_ratio = wl["width"] / wl["height"]
 cam = L.host.camera(su)
 W, H = wl["width"], wl["height"]
 accum = torch.zeros(H, W, 3, dtype=torch.float32, device="cuda")

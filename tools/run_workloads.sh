@@ -1,5 +1,8 @@
+#!/bin/bash
+# GPU box: bench.py on the workloads other than the headline one, and the timing of rt_bvh_build; JSON lines under
+# gpurun_out/.
 set -o pipefail
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 for w in weekend cornell smoke; do
   timeout -k 10 200 python bench.py --workload $w --steps 3 --warmup 1 --cpu-spp 0 > gpurun_out/w_$w.json 2> gpurun_out/w_$w.err || exit 1
   echo "$w done"
