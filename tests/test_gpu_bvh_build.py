@@ -24,6 +24,18 @@ def test_tokens_equal_the_oracles_small(gpu, orc, name, boxes):
     assert ms > 0.0
 
 
+@pytest.mark.parametrize("n", [4, 63, 64, 65, 127, 128, 129, 191, 192, 4095, 4096, 4097, 8193, 12345])
+def test_tokens_equal_the_oracles_at_block_boundaries(gpu, orc, n):
+    # node boxes come from unions over 64-leaf blocks and a table over whole blocks: sizes around the block size, with
+    # clustered centres so that ranges of every length occur
+    rng = np.random.default_rng(n)
+    c = rng.normal(0.0, 1.0, (n, 3)) + rng.integers(0, 3, (n, 1)) * 10.0
+    h = rng.uniform(0.0, 0.2, (n, 3))
+    boxes = np.concatenate([c - h, c + h], axis=1)
+    got, _ = gpu.bvh_build(boxes)
+    assert same_tokens(got, orc.lbvh_tokens(boxes))
+
+
 @pytest.mark.parametrize("n", [100_000, 2_000_000])
 def test_tokens_equal_the_oracles_large(gpu, orc, n):
     rng = np.random.default_rng(n)
