@@ -86,3 +86,20 @@ def test_cli_render_checkpoint_resume_is_bit_identical(gpu, tmp_path):
     assert not np.array_equal(a, imageio.decode_png(open(part, "rb").read()))
     with pytest.raises(ValueError):  # other parameters: the checkpoint is refused
         render.main(common[:2] + ["--width", "64", "--spp", "12", "--out", part, "--checkpoint", ck, "--quiet"])
+
+
+@pytest.mark.gpu
+def test_cli_tree_options_give_the_same_picture(gpu, tmp_path):
+    # the mesh scene with the reference's tree, the widest-axis tree and the tree built on the GPU: the same samples
+    # hit the same primitives whatever the tree (up to exact ties in t), so the pictures agree pixel for pixel but for
+    # a handful of pixels
+    common = ["--scene", "12", "--triangles", "20000", "--width", "160", "--height", "90", "--spp", "8", "--quiet"]
+    pics = {}
+    for tree in ("reference", "widest", "lbvh"):
+        out = str(tmp_path / (tree + ".png"))
+        assert render.main(common + ["--bvh", tree, "--out", out]) == 0
+        pics[tree] = imageio.decode_png(open(out, "rb").read()).astype(np.int32)
+        assert pics[tree].shape == (90, 160, 3)
+    for tree in ("widest", "lbvh"):
+        differs = (pics[tree] != pics["reference"]).any(axis=2)
+        assert differs.mean() < 0.01, "%s: %d pixels differ" % (tree, differs.sum())
