@@ -161,6 +161,43 @@ pub fn flatten_bvh(n: &BVHNode, f: &mut Flat) {                             // s
     if !Arc::ptr_eq(&n.left, &n.right) { n.right.flatten(f); }              // span-1 node holds one object twice (:39-44)
     f.nodes[at].link = f.nodes.len() as u32;
 }
+/// A tree built by `rt_bvh_build` on the GPU instead of `BVHNode::new` (src/bvh.rs:17-98): the object list and the
+/// tree as pre-order tokens. It implements `Hittable` only to be flattened and bounded; `hit` is never called on
+/// the host. Restates `DeviceBvh` of raytracer_amd/csrc/host/scene.hpp.
+pub struct DeviceBvh { pub objects: Vec<Arc<dyn Hittable>>, pub tokens: Vec<RtNode>, pub _box: AABB }
+impl DeviceBvh {
+    pub fn new(objects: Vec<Arc<dyn Hittable>>, time0: f64, time1: f64) -> Result<DeviceBvh, String> {
+        let mut boxes = Vec::with_capacity(objects.len() * 6);
+        let mut whole = AABB::default();
+        for (i, o) in objects.iter().enumerate() {
+            let mut b = AABB::default();
+            if !o.bounding_box(time0, time1, &mut b) { return Err("object without a bounding box".into()); }   // src/bvh.rs:83-87
+            boxes.extend_from_slice(&[b._min.x, b._min.y, b._min.z, b._max.x, b._max.y, b._max.z]);
+            whole = if i == 0 { b } else { surrounding_box(&whole, &b) };                                       // src/aabb.rs:33-50
+        }
+        let mut tokens = vec![RtNode { lo: [0.0; 3], hi: [0.0; 3], meta: 0, link: 0 }; 2 * objects.len() - 1];
+        check(unsafe { rt_bvh_build(boxes.as_ptr(), objects.len() as u64, tokens.as_mut_ptr(), std::ptr::null_mut()) })?;
+        Ok(DeviceBvh { objects, tokens, _box: whole })
+    }
+}
+pub fn flatten_device_bvh(n: &DeviceBvh, f: &mut Flat) {
+    let mut open: Vec<(usize, u32)> = Vec::new();                           // (entry, token after its subtree)
+    for (k, t) in n.tokens.iter().enumerate() {
+        if t.meta == RT_BVH_TOKEN_LEAF {
+            n.objects[t.link as usize].flatten(f);
+        } else {
+            let at = f.push_node(RT_N_INNER, 0);
+            f.nodes[at].lo = t.lo;
+            f.nodes[at].hi = t.hi;
+            open.push((at, t.link));
+        }
+        while let Some(&(at, end)) = open.last() {
+            if end as usize != k + 1 { break; }
+            f.nodes[at].link = f.nodes.len() as u32;
+            open.pop();
+        }
+    }
+}
 pub fn flatten_translate(t: &Translate, f: &mut Flat) {                     // src/hittable.rs:262-265
     let x = RtXform { kind: 0, depth: 0, anc: [RT_NONE; 4], inst_id: 0, _pad: 0, sin_theta: 0.0, cos_theta: 0.0, offset: a3(&t.offset) };
     f.push_xform(x, &*t.ptr);
