@@ -222,6 +222,37 @@ int rt_render_device(RtScene* scene, const RtCamera* cam, const RtRenderParams* 
 int rt_render_work(RtScene* scene, const RtCamera* cam, const RtRenderParams* params, float* accum_rgb_dev, void* stream,
                    RtRenderStats* stats, uint64_t* work);
 
+/* What one iteration of ray_color (src/color.rs:41-62) does with one ray. */
+typedef struct RtPathStep {
+    double emitted[3];           /* what the iteration adds to the pixel at throughput 1: the background on a
+                                    miss (:41-43), Material::emitted at a hit (:50) */
+    double attenuation[3];       /* Material::scatter's attenuation (:52-54); 0 when not scattered */
+    double o[3], d[3];           /* the scattered ray (its time is the incoming ray's); 0 when not scattered */
+    double t;                    /* closest hit, as RtHit; 0 on a miss */
+    uint32_t prim_id, sub;       /* as RtHit */
+    uint32_t scattered;          /* 1: scatter returned true and the path goes on */
+    uint32_t _pad;
+} RtPathStep;
+
+#define RT_PROFILE_OWN (-1)
+
+/* One iteration of the bounce loop of ray_color (src/color.rs:41-62) for n caller-supplied rays, run by the very
+ * launches rt_render makes for a bounce (the closest-hit kernel, then the shade kernel) instead of the stand-alone
+ * kernels behind rt_trace_*: rays are laid out as the render path's ray records with throughput 1, and the
+ * outcome of each is read back from the hit slots, the radiance columns and the survivors' records. Each ray's
+ * (pixel, sample, bounce) keys its random draws as in a render with these `params` (width, height, sample range,
+ * seed, background, max_depth); rays must have tmin = 0.0001 and tmax = +inf (src/color.rs:41), pixel < width *
+ * height, sample in [sample_begin, sample_end), bounce < max_depth, and no two rays of one bounce may share
+ * (pixel, sample). `profile` selects the variant of the closest-hit kernel: RT_PROFILE_OWN = the one rt_render
+ * runs for this scene; otherwise a bit set (1: boxes alone inside wrappers handled in one step, 2: general walk of
+ * medium boundaries, 4: lanes leave the box phase by vote) which must be one of 0, 1, 3, 4, 5, 7 and able to
+ * handle the scene's media (RT_E_INVALID otherwise). `work`, when not NULL, receives the traversal work of the
+ * closest-hit launches (10 words as in rt_trace_work). Host buffers. */
+int rt_path_step(RtScene* scene, const RtRenderParams* params, int profile, const RtRay* rays, uint64_t n, RtPathStep* out,
+                 uint64_t* work);
+/* The profile rt_render runs on this scene (the bit set described above), or a negative RtError. */
+int rt_scene_profile(const RtScene* scene);
+
 /* Replaces the gamma / clamp / u8 conversion (src/main.rs:212-225): out =
  * clamp(sqrt(accum / spp), 0, 0.999) * 255 as u8. Host buffers / device buffers. */
 int rt_resolve_u8(const float* accum_rgb, uint32_t width, uint32_t height, uint64_t spp, uint8_t* rgb_out);

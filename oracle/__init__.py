@@ -53,6 +53,8 @@ class Oracle:
         L.orc_render.restype = i
         L.orc_harvest.argtypes = [vp, P(abi.RtCamera), P(abi.RtRenderParams), i, u32, u64, u64, vp, P(u64)]
         L.orc_harvest.restype = i
+        L.orc_path_step.argtypes = [vp, P(abi.RtRenderParams), i, vp, u64, vp]
+        L.orc_path_step.restype = i
         L.orc_lbvh_tokens.argtypes = [vp, u64, vp]
         L.orc_lbvh_tokens.restype = i
 
@@ -101,6 +103,13 @@ class Oracle:
                                 recs.ctypes.data if records else None, stats)
         self.api.check(rc)
         return hits, recs, dict(zip(STAT_NAMES, stats))
+
+    def path_step(self, scene, params, rays, mode=AABB_TIGHT):
+        """One iteration of ray_color per ray (closest hit, emitted, scatter): the checker of rt_path_step."""
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY_DTYPE)
+        out = np.zeros(rays.shape[0], dtype=abi.PATHSTEP_DTYPE)
+        self.api.check(self.lib.orc_path_step(scene, C.byref(params), mode, rays.ctypes.data, rays.shape[0], out.ctypes.data))
+        return out
 
     def make_params(self, width, height, s0, s1, background, seed=0x5EED, max_depth=50, samples_per_batch=0):
         p = abi.RtRenderParams()

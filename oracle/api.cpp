@@ -218,6 +218,40 @@ int orc_render(OrcScene* s, const RtCamera* cam_in, const RtRenderParams* p, int
     return 0;
 }
 
+// One iteration of ray_color (src/color.rs:41-62) per ray: the checker of rt_path_step. The ray's (pixel, sample,
+// bounce) key the medium draw inside world.hit and the scatter stream, as in ray_color above.
+int orc_path_step(OrcScene* s, const RtRenderParams* p, int aabb_mode, const RtRay* rays, uint64_t n, RtPathStep* out) {
+    tls.aabb_mode = aabb_mode;
+    tls.rng.seed = p->seed;
+    const Color background(p->background[0], p->background[1], p->background[2]);
+    for (uint64_t i = 0; i < n; ++i) {
+        const RtRay& q = rays[i];
+        Ray r{Point(q.o[0], q.o[1], q.o[2]), Vec3(q.d[0], q.d[1], q.d[2]), q.tm};
+        tls.pixel = q.pixel; tls.sample = q.sample; tls.bounce = q.bounce;
+        RtPathStep& o = out[i];
+        std::memset(&o, 0, sizeof o);
+        o.prim_id = RT_MISS;
+        HitRecord rec;
+        if (!s->world->hit(r, 0.0001, INF, rec)) {  // :41-43
+            put(o.emitted, background);
+            continue;
+        }
+        o.prim_id = rec.prim_id;
+        o.sub = rec.side | ((rec.inst_id + 1u) << 8);
+        o.t = rec.t;
+        Ray scattered{Vec3::ones(), Vec3::ones(), 0.0};
+        Color attenuation(0.0, 0.0, 0.0);
+        put(o.emitted, rec.mat_ptr->emitted(rec.u, rec.v, rec.p));  // :50
+        tls.rng.set(tls.pixel, tls.sample, tls.bounce, STREAM_SCATTER);
+        if (!rec.mat_ptr->scatter(r, rec, attenuation, scattered)) continue;  // :52-57
+        if ((int)q.bounce + 1 >= (int)p->max_depth) continue;  // ray_color(depth - 1) with depth - 1 == 0 is black (:37-39)
+        o.scattered = 1u;
+        put(o.attenuation, attenuation);
+        put(o.o, scattered.orig); put(o.d, scattered.dire);
+    }
+    return 0;
+}
+
 // Traces n_paths path samples spread over the image and records every ray handed to world.hit at
 // bounces <= max_bounce (primary rays and their continuations), up to max_rays.
 int orc_harvest(OrcScene* s, const RtCamera* cam_in, const RtRenderParams* p, int aabb_mode, uint32_t max_bounce,

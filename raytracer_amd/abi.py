@@ -98,6 +98,11 @@ class RtHitRecord(C.Structure):
                 ("prim_id", C.c_uint32), ("sub", C.c_uint32), ("mat", C.c_uint32), ("front_face", C.c_uint32)]
 
 
+class RtPathStep(C.Structure):
+    _fields_ = [("emitted", d3), ("attenuation", d3), ("o", d3), ("d", d3), ("t", C.c_double),
+                ("prim_id", C.c_uint32), ("sub", C.c_uint32), ("scattered", C.c_uint32), ("_pad", C.c_uint32)]
+
+
 class RtCamera(C.Structure):
     _fields_ = [("orig", d3), ("lower_left_corner", d3), ("horizontal", d3), ("vertical", d3), ("u", d3), ("v", d3),
                 ("lens_radius", C.c_double), ("time0", C.c_double), ("time1", C.c_double)]
@@ -140,11 +145,15 @@ RAY_DTYPE = np.dtype([("o", "<f8", 3), ("d", "<f8", 3), ("tm", "<f8"), ("tmin", 
 HIT_DTYPE = np.dtype([("prim_id", "<u4"), ("sub", "<u4"), ("t", "<f8"), ("u", "<f8"), ("v", "<f8")])
 HITREC_DTYPE = np.dtype([("p", "<f8", 3), ("normal", "<f8", 3), ("t", "<f8"), ("u", "<f8"), ("v", "<f8"),
                          ("prim_id", "<u4"), ("sub", "<u4"), ("mat", "<u4"), ("front_face", "<u4")])
+PATHSTEP_DTYPE = np.dtype([("emitted", "<f8", 3), ("attenuation", "<f8", 3), ("o", "<f8", 3), ("d", "<f8", 3), ("t", "<f8"),
+                           ("prim_id", "<u4"), ("sub", "<u4"), ("scattered", "<u4"), ("_pad", "<u4")])
+RT_PROFILE_OWN = -1
 NODE_DTYPE = np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("meta", "<u4"), ("link", "<u4")])
 assert NODE_DTYPE.itemsize == C.sizeof(RtNode) == 32
 assert RAY_DTYPE.itemsize == C.sizeof(RtRay) == 88
 assert HIT_DTYPE.itemsize == C.sizeof(RtHit) == 32
 assert HITREC_DTYPE.itemsize == C.sizeof(RtHitRecord) == 88
+assert PATHSTEP_DTYPE.itemsize == C.sizeof(RtPathStep) == 120
 
 NODE_KINDS = {0: "inner", 1: "sphere", 2: "msphere", 3: "rect", 4: "box6", 5: "triangle", 6: "xf_enter", 7: "xf_exit",
               8: "medium"}

@@ -726,6 +726,62 @@ __global__ void __launch_bounds__(SHADE_BLOCK, RT_SHADE_WAVES) k_shade(DevScene 
     }
 }
 
+// ---- one bounce on caller-supplied rays (rt_path_step) ------------------------------------------------
+// pack: ray idx[k] of the caller's array becomes record k of the current record array, with throughput 1 and the
+// slot its (pixel, sample) has in a render of these parameters; its radiance columns start at zero.
+__global__ void __launch_bounds__(BLOCK) k_step_pack(const RtRay* __restrict__ rays, const uint32_t* __restrict__ idx, uint32_t n,
+                                                     uint32_t npix, uint32_t sample_begin, PathState P, uint32_t cur,
+                                                     uint32_t* __restrict__ slot_to_ray) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t i = idx[k];
+    const RtRay* q = rays + i;
+    const uint32_t slot = (q->sample - sample_begin) * npix + q->pixel;
+    store_ray(P.rec[cur] + k, v3p(q->o), v3p(q->d), q->tm, slot, v3(1.0, 1.0, 1.0));
+    P.lr[slot] = 0.0; P.lg[slot] = 0.0; P.lb[slot] = 0.0;
+    slot_to_ray[slot] = i;
+}
+// unpack, first half: the closest hit the extend launch stored for record k and what the shade launch added to the
+// ray's radiance columns
+__global__ void __launch_bounds__(BLOCK) k_step_unpack_hits(DevScene S, const uint32_t* __restrict__ idx, uint32_t n, PathState P,
+                                                            uint32_t cur, RtPathStep* __restrict__ out) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const uint4 h = *reinterpret_cast<const uint4*>(P.hit + k);
+    Cand best;
+    best.t = __hiloint2double((int)h.y, (int)h.x); best.ref = h.z; best.aux = h.w;
+    const uint32_t slot = P.rec[cur][k].slot;
+    RtPathStep o;
+    o.emitted[0] = P.lr[slot]; o.emitted[1] = P.lg[slot]; o.emitted[2] = P.lb[slot];
+    for (int c = 0; c < 3; ++c) { o.attenuation[c] = 0.0; o.o[c] = 0.0; o.d[c] = 0.0; }
+    o.t = 0.0; o.prim_id = RT_MISS; o.sub = 0u; o.scattered = 0u; o._pad = 0u;
+    if (best.ref != RT_MISS) {
+        o.t = best.t;
+        hit_ids(S, best, o.prim_id, o.sub);
+    }
+    out[idx[k]] = o;
+}
+// unpack, second half: the records the shade launch appended to the other array are the scattered rays; with an
+// incoming throughput of 1 the stored throughput is the attenuation itself
+__global__ void __launch_bounds__(BLOCK) k_step_unpack_survivors(PathState P, uint32_t next, const uint32_t* __restrict__ counts,
+                                                                 const uint32_t* __restrict__ slot_to_ray, RtPathStep* __restrict__ out) {
+    const uint32_t n = counts[next];
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n; k += stride) {
+        V3 o, d, T;
+        double tm;
+        uint32_t slot;
+        load_ray64(P.rec[next] + k, o, d, tm, slot);
+        if (slot == DEAD_SLOT) continue;
+        load_throughput(P.rec[next] + k, T);
+        RtPathStep* r = out + slot_to_ray[slot];
+        r->o[0] = o.x; r->o[1] = o.y; r->o[2] = o.z;
+        r->d[0] = d.x; r->d[1] = d.y; r->d[2] = d.z;
+        r->attenuation[0] = T.x; r->attenuation[1] = T.y; r->attenuation[2] = T.z;
+        r->scattered = 1u;
+    }
+}
+
 // ---- accumulate: sum the batch's samples of each pixel in sample order ---------------------------
 __global__ void __launch_bounds__(BLOCK) k_accumulate(RenderConst C, PathState P, float* __restrict__ accum) {
     const uint32_t stride = gridDim.x * BLOCK;

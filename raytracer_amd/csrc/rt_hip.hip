@@ -56,7 +56,14 @@ struct RtScene {
     bool extend_lds = false, shade_lds = false;  // which variant of each kernel this scene runs
     bool shade_sort = false;
     bool box_media = false;   // some box of six sides sits alone inside wrappers (on its own or as a medium's boundary)
+    bool general_media = false;  // some medium's boundary is neither one sphere nor one box alone inside wrappers
+    bool boxed_media = false;    // some medium's boundary is one box alone inside zero or more wrappers
     int profile = 3;          // extend kernel profile (bits as in kernels.h): 1 box_media, 2 general boundary walk, 4 vote
+    // Device staging areas of the entry points that take host buffers, kept between calls and grown on demand
+    // (rt_trace_*, rt_render, rt_path_step): [0] input, [1] output, [2] small extras.
+    void* stage[3] = {nullptr, nullptr, nullptr};
+    size_t stage_bytes[3] = {0, 0, 0};
+    hipEvent_t ev_trace[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -216,6 +223,47 @@ int check_render_args(const RtScene* s, const RtCamera* cam, const RtRenderParam
     return RT_OK;
 }
 
+// The two launches of one bounce, shared by the render loop and rt_path_step. `profile`: bits as in kernels.h.
+void launch_extend(RtScene* s, int profile, bool count_work, const RenderConst& C, uint32_t cur, uint32_t bounce, hipStream_t stream) {
+    Workspace& w = s->ws;
+    const dim3 eg(s->grid_extend);
+    unsigned long long* wk = count_work ? w.ray_total + 1 : nullptr;
+#define RT_LAUNCH_EXTEND(W, L, PR) hipLaunchKernelGGL((rtd::k_extend<W, L, PR>), eg, dim3(rtd::extend_block(L, PR)), s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk)
+#define RT_LAUNCH_EXTEND_P(PR) do { if (count_work) { if (s->extend_lds) RT_LAUNCH_EXTEND(true, true, PR); else RT_LAUNCH_EXTEND(true, false, PR); } \
+                                    else { if (s->extend_lds) RT_LAUNCH_EXTEND(false, true, PR); else RT_LAUNCH_EXTEND(false, false, PR); } } while (0)
+    switch (profile) {
+        case 0: RT_LAUNCH_EXTEND_P(0); break;
+        case 1: RT_LAUNCH_EXTEND_P(1); break;
+        case 3: RT_LAUNCH_EXTEND_P(3); break;
+        case 4: RT_LAUNCH_EXTEND_P(4); break;
+        case 5: RT_LAUNCH_EXTEND_P(5); break;
+        default: RT_LAUNCH_EXTEND_P(7); break;
+    }
+#undef RT_LAUNCH_EXTEND_P
+#undef RT_LAUNCH_EXTEND
+}
+
+void launch_shade(RtScene* s, const RenderConst& C, uint32_t cur, uint32_t bounce, hipStream_t stream) {
+    Workspace& w = s->ws;
+    const dim3 sg(std::min(s->grid_shade, (C.n_slots + rtd::SHADE_BLOCK - 1) / rtd::SHADE_BLOCK)), sb(rtd::SHADE_BLOCK);
+#define RT_LAUNCH_SHADE(L, Q) hipLaunchKernelGGL((rtd::k_shade<L, Q>), sg, sb, s->lds_bytes_shade, stream, s->S, s->plan_shade, C, w.P, w.counts, cur, bounce, w.ray_total)
+    if (s->shade_lds) { if (s->shade_sort) RT_LAUNCH_SHADE(true, true); else RT_LAUNCH_SHADE(true, false); }
+    else { if (s->shade_sort) RT_LAUNCH_SHADE(false, true); else RT_LAUNCH_SHADE(false, false); }
+#undef RT_LAUNCH_SHADE
+}
+
+// A device staging area of the scene, at least `bytes` long (contents are not kept when it grows).
+int stage_buffer(RtScene* s, int which, size_t bytes, void** out) {
+    if (s->stage_bytes[which] < bytes) {
+        if (s->stage[which]) { HIP_TRY(hipFree(s->stage[which])); s->stage[which] = nullptr; s->stage_bytes[which] = 0; }
+        const size_t want = std::max(bytes, (size_t)1 << 16);
+        HIP_TRY(hipMalloc(&s->stage[which], want));
+        s->stage_bytes[which] = want;
+    }
+    *out = s->stage[which];
+    return RT_OK;
+}
+
 int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* accum_dev, hipStream_t stream,
                      RtRenderStats* stats, uint64_t* work = nullptr) {
     if (int rc = bind_device(s)) return rc;
@@ -267,31 +315,9 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         for (uint32_t bounce = 0; bounce < p->max_depth; ++bounce) {
             const uint32_t cur = bounce & 1u;
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
-            {
-                const dim3 eg(s->grid_extend);
-                unsigned long long* wk = work ? w.ray_total + 1 : nullptr;
-#define RT_LAUNCH_EXTEND(W, L, PR) hipLaunchKernelGGL((rtd::k_extend<W, L, PR>), eg, dim3(rtd::extend_block(L, PR)), s->lds_bytes, stream, s->S, s->plan, C, w.P, w.counts, cur, bounce, wk)
-#define RT_LAUNCH_EXTEND_P(PR) do { if (work) { if (s->extend_lds) RT_LAUNCH_EXTEND(true, true, PR); else RT_LAUNCH_EXTEND(true, false, PR); } \
-                                    else { if (s->extend_lds) RT_LAUNCH_EXTEND(false, true, PR); else RT_LAUNCH_EXTEND(false, false, PR); } } while (0)
-                switch (s->profile) {
-                    case 0: RT_LAUNCH_EXTEND_P(0); break;
-                    case 1: RT_LAUNCH_EXTEND_P(1); break;
-                    case 3: RT_LAUNCH_EXTEND_P(3); break;
-                    case 4: RT_LAUNCH_EXTEND_P(4); break;
-                    case 5: RT_LAUNCH_EXTEND_P(5); break;
-                    default: RT_LAUNCH_EXTEND_P(7); break;
-                }
-#undef RT_LAUNCH_EXTEND_P
-#undef RT_LAUNCH_EXTEND
-            }
+            launch_extend(s, s->profile, work != nullptr, C, cur, bounce, stream);
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
-            {
-                const dim3 sg(std::min(s->grid_shade, (C.n_slots + rtd::SHADE_BLOCK - 1) / rtd::SHADE_BLOCK)), sb(rtd::SHADE_BLOCK);
-#define RT_LAUNCH_SHADE(L, Q) hipLaunchKernelGGL((rtd::k_shade<L, Q>), sg, sb, s->lds_bytes_shade, stream, s->S, s->plan_shade, C, w.P, w.counts, cur, bounce, w.ray_total)
-                if (s->shade_lds) { if (s->shade_sort) RT_LAUNCH_SHADE(true, true); else RT_LAUNCH_SHADE(true, false); }
-                else { if (s->shade_sort) RT_LAUNCH_SHADE(false, true); else RT_LAUNCH_SHADE(false, false); }
-#undef RT_LAUNCH_SHADE
-            }
+            launch_shade(s, C, cur, bounce, stream);
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
         }
         hipLaunchKernelGGL(rtd::k_accumulate, dim3(grid_for(s, npix)), dim3(rtd::BLOCK), 0, stream, C, w.P, accum_dev);
@@ -357,15 +383,16 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
             s->box_media = alone;
         }
         bool general_media = false;  // a medium whose boundary is neither one sphere nor one box alone inside wrappers
-        for (uint64_t i = 0; i < d->n_nodes && !general_media; ++i) {
+        for (uint64_t i = 0; i < d->n_nodes; ++i) {
             if ((d->nodes[i].meta & 15u) != RT_N_MEDIUM) continue;
             const uint64_t link = d->nodes[i].link;
             if (link == i + 2 && (d->nodes[i + 1].meta & 15u) == RT_N_SPHERE) continue;
             uint64_t j = i + 1;
             while (j + 1 < link && (d->nodes[j].meta & 15u) == RT_N_XF_ENTER) ++j;
             const bool boxed = (d->nodes[j].meta & 15u) == RT_N_BOX6 && link == i + 2 + 2 * (j - (i + 1));
-            if (!boxed) general_media = true;
+            if (!boxed) general_media = true; else s->boxed_media = true;
         }
+        s->general_media = general_media;
         s->profile = (general_media ? 3 : (s->box_media ? 1 : 0)) | (d->n_nodes >= 128 ? 4 : 0);
         if (general_media) s->box_media = true;  // profile 3 compiles both in
         // LDS plans: a kernel runs its LDS variant when every table it reads (all but images / texels) fits
@@ -524,6 +551,8 @@ void rt_scene_destroy(RtScene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (void* p : s->allocs) (void)hipFree(p);
+    for (void* p : s->stage) if (p) (void)hipFree(p);
+    for (hipEvent_t e : s->ev_trace) if (e) (void)hipEventDestroy(e);
     free_workspace(s->ws);
     delete s;
 }
@@ -549,75 +578,60 @@ int rt_trace_closest_device(RtScene* s, const RtRay* rays_dev, uint64_t n, uint6
 
 namespace {
 
-// Shared body of rt_trace_closest / rt_trace_records / rt_trace_work: host buffers in and out.
+// Shared body of rt_trace_closest / rt_trace_records / rt_trace_work: host buffers in and out, staged through the
+// scene's device staging areas (allocated once, grown on demand).
 int trace_host(RtScene* s, const RtRay* rays, uint64_t n, uint64_t seed, RtHit* hits, RtHitRecord* recs, uint64_t* work,
                RtTraceStats* stats) {
     if (!s || (n && !rays) || (n && !hits && !recs)) return rt::set_error(RT_E_INVALID, "null argument");
     if (stats) stats->ms_kernel = 0.0;
     if (work) std::memset(work, 0, kWorkWords * sizeof(uint64_t));
     if (n == 0) return RT_OK;
+    if (n >= (1ull << 32)) return rt::set_error(RT_E_INVALID, "too many rays in one call");
     if (int rc = bind_device(s)) return rc;
-    RtRay* d_rays = nullptr;
-    void* d_out = nullptr;
-    unsigned long long* d_work = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
     const size_t out_bytes = n * (recs ? sizeof(RtHitRecord) : sizeof(RtHit));
-    int rc = RT_OK;
-    auto cleanup = [&]() {
-        if (d_rays) (void)hipFree(d_rays);
-        if (d_out) (void)hipFree(d_out);
-        if (d_work) (void)hipFree(d_work);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-    };
-    auto body = [&]() -> int {
-        HIP_TRY(hipMalloc((void**)&d_rays, n * sizeof(RtRay)));
-        HIP_TRY(hipMalloc(&d_out, out_bytes));
-        HIP_TRY(hipMemcpy(d_rays, rays, n * sizeof(RtRay), hipMemcpyHostToDevice));
-        if (work) {
-            HIP_TRY(hipMalloc((void**)&d_work, kWorkWords * sizeof(unsigned long long)));
-            HIP_TRY(hipMemset(d_work, 0, kWorkWords * sizeof(unsigned long long)));
-        }
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        if (n >= (1ull << 32)) return rt::set_error(RT_E_INVALID, "too many rays in one call");
-        if (int rc2 = ensure_workspace(s, 0)) return rc2;
-        uint32_t* cursor = s->ws.counts + 3;
-        HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t), nullptr));
-        const dim3 grid(trace_grid(s, n)), block(rtd::TRACE_BLOCK);
-        HIP_TRY(hipEventRecord(e0, nullptr));
-        RtHit* oh = recs ? nullptr : (RtHit*)d_out;
-        RtHitRecord* orc = recs ? (RtHitRecord*)d_out : nullptr;
+    void *d_rays_v = nullptr, *d_out = nullptr, *d_work_v = nullptr;
+    if (int rc = stage_buffer(s, 0, n * sizeof(RtRay), &d_rays_v)) return rc;
+    if (int rc = stage_buffer(s, 1, out_bytes, &d_out)) return rc;
+    if (int rc = stage_buffer(s, 2, kWorkWords * sizeof(unsigned long long), &d_work_v)) return rc;
+    RtRay* d_rays = static_cast<RtRay*>(d_rays_v);
+    unsigned long long* d_work = work ? static_cast<unsigned long long*>(d_work_v) : nullptr;
+    for (hipEvent_t& e : s->ev_trace)
+        if (!e) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipMemcpy(d_rays, rays, n * sizeof(RtRay), hipMemcpyHostToDevice));
+    if (work) HIP_TRY(hipMemset(d_work, 0, kWorkWords * sizeof(unsigned long long)));
+    if (int rc = ensure_workspace(s, 0)) return rc;
+    uint32_t* cursor = s->ws.counts + 3;
+    HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t), nullptr));
+    const dim3 grid(trace_grid(s, n)), block(rtd::TRACE_BLOCK);
+    HIP_TRY(hipEventRecord(s->ev_trace[0], nullptr));
+    RtHit* oh = recs ? nullptr : (RtHit*)d_out;
+    RtHitRecord* orc = recs ? (RtHitRecord*)d_out : nullptr;
 #define RT_LAUNCH_TRACE(R, W, L) hipLaunchKernelGGL((rtd::k_trace<R, W, L>), grid, block, s->lds_bytes, nullptr, s->S, s->plan, d_rays, n, seed, oh, orc, cursor, d_work)
-        const int variant = (recs ? 4 : 0) | (work ? 2 : 0) | (s->extend_lds ? 1 : 0);
-        switch (variant) {
-            case 0: RT_LAUNCH_TRACE(false, false, false); break;
-            case 1: RT_LAUNCH_TRACE(false, false, true); break;
-            case 2: RT_LAUNCH_TRACE(false, true, false); break;
-            case 3: RT_LAUNCH_TRACE(false, true, true); break;
-            case 4: RT_LAUNCH_TRACE(true, false, false); break;
-            case 5: RT_LAUNCH_TRACE(true, false, true); break;
-            case 6: RT_LAUNCH_TRACE(true, true, false); break;
-            default: RT_LAUNCH_TRACE(true, true, true); break;
-        }
+    const int variant = (recs ? 4 : 0) | (work ? 2 : 0) | (s->extend_lds ? 1 : 0);
+    switch (variant) {
+        case 0: RT_LAUNCH_TRACE(false, false, false); break;
+        case 1: RT_LAUNCH_TRACE(false, false, true); break;
+        case 2: RT_LAUNCH_TRACE(false, true, false); break;
+        case 3: RT_LAUNCH_TRACE(false, true, true); break;
+        case 4: RT_LAUNCH_TRACE(true, false, false); break;
+        case 5: RT_LAUNCH_TRACE(true, false, true); break;
+        case 6: RT_LAUNCH_TRACE(true, true, false); break;
+        default: RT_LAUNCH_TRACE(true, true, true); break;
+    }
 #undef RT_LAUNCH_TRACE
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(e1, nullptr));
-        HIP_TRY(hipDeviceSynchronize());
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        if (stats) stats->ms_kernel = ms;
-        HIP_TRY(hipMemcpy(recs ? (void*)recs : (void*)hits, d_out, out_bytes, hipMemcpyDeviceToHost));
-        if (work) {
-            unsigned long long tmp[kWorkWords];
-            HIP_TRY(hipMemcpy(tmp, d_work, sizeof tmp, hipMemcpyDeviceToHost));
-            for (int k = 0; k < kWorkWords; ++k) work[k] = tmp[k];
-        }
-        return RT_OK;
-    };
-    rc = body();
-    cleanup();
-    return rc;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev_trace[1], nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_trace[0], s->ev_trace[1]));
+    if (stats) stats->ms_kernel = ms;
+    HIP_TRY(hipMemcpy(recs ? (void*)recs : (void*)hits, d_out, out_bytes, hipMemcpyDeviceToHost));
+    if (work) {
+        unsigned long long tmp[kWorkWords];
+        HIP_TRY(hipMemcpy(tmp, d_work, sizeof tmp, hipMemcpyDeviceToHost));
+        for (int k = 0; k < kWorkWords; ++k) work[k] = tmp[k];
+    }
+    return RT_OK;
 }
 
 }  // namespace
@@ -637,6 +651,95 @@ int rt_trace_work(RtScene* s, const RtRay* rays, uint64_t n, uint64_t seed, RtHi
     return trace_host(s, rays, n, seed, out, nullptr, work, nullptr);
 }
 
+int rt_scene_profile(const RtScene* s) {
+    if (!s) return rt::set_error(RT_E_INVALID, "null argument");
+    return s->profile;
+}
+
+int rt_path_step(RtScene* s, const RtRenderParams* p, int profile, const RtRay* rays, uint64_t n, RtPathStep* out, uint64_t* work) {
+    if (!s || !p || (n && (!rays || !out))) return rt::set_error(RT_E_INVALID, "null argument");
+    if (work) std::memset(work, 0, kWorkWords * sizeof(uint64_t));
+    if (profile == RT_PROFILE_OWN) profile = s->profile;
+    if (profile != 0 && profile != 1 && profile != 3 && profile != 4 && profile != 5 && profile != 7)
+        return rt::set_error(RT_E_INVALID, "profile must be one of 0, 1, 3, 4, 5, 7");
+    if (s->general_media && !(profile & 2)) return rt::set_error(RT_E_INVALID, "the scene's media need the general boundary walk (profile bit 2)");
+    if (s->boxed_media && !(profile & 3)) return rt::set_error(RT_E_INVALID, "the scene's box-bounded media need profile bit 1 or 2");
+    if (p->width < 2 || p->height < 2 || p->sample_end < p->sample_begin || p->max_depth > 0xFFFFu)
+        return rt::set_error(RT_E_INVALID, "bad render parameters");
+    if (n == 0) return RT_OK;
+    const uint64_t npix = (uint64_t)p->width * p->height;
+    const uint64_t n_slots = npix * (p->sample_end - p->sample_begin);
+    if (n_slots == 0 || n_slots + shade_padding(s) >= (1ull << 32) - 2) return rt::set_error(RT_E_INVALID, "sample range empty or too large");
+    // group the rays by bounce; within a group (pixel, sample) must be unique: a slot holds one path
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    std::vector<std::pair<uint32_t, uint64_t>> groups;  // (bounce, rays)
+    {
+        std::vector<std::pair<uint64_t, uint32_t>> keyed((size_t)n);  // (bounce << 32 | slot, ray)
+        for (uint64_t i = 0; i < n; ++i) {
+            const RtRay& q = rays[i];
+            if (q.tmin != 0.0001 || q.tmax != rtd::D_INF) return rt::set_error(RT_E_INVALID, "rays must have tmin = 0.0001 and tmax = +inf");
+            if (q.pixel >= npix || q.sample < p->sample_begin || q.sample >= p->sample_end || q.bounce >= p->max_depth)
+                return rt::set_error(RT_E_INVALID, "ray key outside the render parameters");
+            keyed[(size_t)i] = {((uint64_t)q.bounce << 32) | ((uint64_t)(q.sample - p->sample_begin) * npix + q.pixel), (uint32_t)i};
+        }
+        std::sort(keyed.begin(), keyed.end());
+        for (size_t i = 0; i < keyed.size(); ++i) {
+            if (i && keyed[i].first == keyed[i - 1].first) return rt::set_error(RT_E_INVALID, "two rays share (pixel, sample, bounce)");
+            const uint32_t bounce = (uint32_t)(keyed[i].first >> 32);
+            if (groups.empty() || groups.back().first != bounce) groups.push_back({bounce, 0});
+            ++groups.back().second;
+            order.push_back(keyed[i].second);
+        }
+    }
+    if (int rc = bind_device(s)) return rc;
+    if (int rc = ensure_workspace(s, n_slots)) return rc;
+    void *d_rays_v = nullptr, *d_out_v = nullptr, *d_idx_v = nullptr;
+    if (int rc = stage_buffer(s, 0, n * sizeof(RtRay), &d_rays_v)) return rc;
+    if (int rc = stage_buffer(s, 1, n * sizeof(RtPathStep), &d_out_v)) return rc;
+    if (int rc = stage_buffer(s, 2, (n + n_slots) * sizeof(uint32_t), &d_idx_v)) return rc;
+    const RtRay* d_rays = static_cast<const RtRay*>(d_rays_v);
+    RtPathStep* d_out = static_cast<RtPathStep*>(d_out_v);
+    uint32_t* d_idx = static_cast<uint32_t*>(d_idx_v);
+    uint32_t* d_slot_to_ray = d_idx + n;
+    Workspace& w = s->ws;
+    hipStream_t stream = nullptr;
+    HIP_TRY(hipMemcpy(d_rays_v, rays, n * sizeof(RtRay), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_idx, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(w.ray_total, 0, (1 + kWorkWords) * sizeof(unsigned long long), stream));
+
+    RenderConst C{};
+    C.seed = p->seed;
+    for (int k = 0; k < 3; ++k) C.bg[k] = p->background[k];
+    C.width = p->width; C.height = p->height; C.npix = (uint32_t)npix;
+    C.max_depth = p->max_depth;
+    C.sample0 = p->sample_begin;
+    uint64_t at = 0;
+    for (const auto& g : groups) {
+        const uint32_t bounce = g.first, ng = (uint32_t)g.second;
+        const uint32_t cur = bounce & 1u;
+        C.n_slots = ng;  // the length of the record array of bounce 0; later bounces read it from counts[cur]
+        const uint32_t counts_host[3] = {cur == 0u ? ng : 0u, cur == 1u ? ng : 0u, 0u};
+        HIP_TRY(hipMemcpyAsync(w.counts, counts_host, sizeof counts_host, hipMemcpyHostToDevice, stream));
+        const uint32_t grid = grid_for(s, ng);
+        hipLaunchKernelGGL(rtd::k_step_pack, dim3(grid), dim3(rtd::BLOCK), 0, stream, d_rays, d_idx + at, ng, (uint32_t)npix, p->sample_begin, w.P, cur, d_slot_to_ray);
+        launch_extend(s, profile, work != nullptr, C, cur, bounce, stream);
+        launch_shade(s, C, cur, bounce, stream);
+        hipLaunchKernelGGL(rtd::k_step_unpack_hits, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, d_idx + at, ng, w.P, cur, d_out);
+        hipLaunchKernelGGL(rtd::k_step_unpack_survivors, dim3(grid), dim3(rtd::BLOCK), 0, stream, w.P, cur ^ 1u, w.counts, d_slot_to_ray, d_out);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));  // counts_host leaves scope; groups are few
+        at += ng;
+    }
+    HIP_TRY(hipMemcpy(out, d_out, n * sizeof(RtPathStep), hipMemcpyDeviceToHost));
+    if (work) {
+        unsigned long long tmp[kWorkWords];
+        HIP_TRY(hipMemcpy(tmp, w.ray_total + 1, sizeof tmp, hipMemcpyDeviceToHost));
+        for (int k = 0; k < kWorkWords; ++k) work[k] = tmp[k];
+    }
+    return RT_OK;
+}
+
 int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* accum_dev, void* stream, RtRenderStats* stats) {
     if (int rc = check_render_args(s, cam, p, accum_dev)) return rc;
     return render_on_stream(s, cam, p, accum_dev, (hipStream_t)stream, stats);
@@ -653,19 +756,13 @@ int rt_render(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* a
     if (int rc = check_render_args(s, cam, p, accum_rgb)) return rc;
     if (int rc = bind_device(s)) return rc;
     const size_t bytes = (size_t)p->width * p->height * 3 * sizeof(float);
-    float* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, bytes));
-    int rc = RT_OK;
-    auto body = [&]() -> int {
-        HIP_TRY(hipMemcpy(d, accum_rgb, bytes, hipMemcpyHostToDevice));
-        if (int r = render_on_stream(s, cam, p, d, nullptr, stats)) return r;
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(accum_rgb, d, bytes, hipMemcpyDeviceToHost));
-        return RT_OK;
-    };
-    rc = body();
-    (void)hipFree(d);
-    return rc;
+    void* d = nullptr;
+    if (int rc = stage_buffer(s, 0, bytes, &d)) return rc;
+    HIP_TRY(hipMemcpy(d, accum_rgb, bytes, hipMemcpyHostToDevice));
+    if (int r = render_on_stream(s, cam, p, static_cast<float*>(d), nullptr, stats)) return r;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(accum_rgb, d, bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
 }
 
 int rt_resolve_u8_device(const float* accum_dev, uint32_t width, uint32_t height, uint64_t spp, uint8_t* out_dev, void* stream) {

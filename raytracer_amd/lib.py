@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")  
 ABI_SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_trace_closest",
     "rt_trace_records", "rt_trace_closest_device", "rt_trace_work", "rt_render", "rt_render_device", "rt_render_work",
-    "rt_resolve_u8",
+    "rt_path_step", "rt_scene_profile", "rt_resolve_u8",
     "rt_resolve_u8_device", "rt_bvh_build",
 )
 HOST_SYMBOLS = (
@@ -82,6 +82,8 @@ class Library:
         L.rt_render.argtypes = [vp, P(abi.RtCamera), P(abi.RtRenderParams), vp, P(abi.RtRenderStats)]
         L.rt_render_device.argtypes = [vp, P(abi.RtCamera), P(abi.RtRenderParams), vp, vp, P(abi.RtRenderStats)]
         L.rt_render_work.argtypes = [vp, P(abi.RtCamera), P(abi.RtRenderParams), vp, vp, P(abi.RtRenderStats), P(u64)]
+        L.rt_path_step.argtypes = [vp, P(abi.RtRenderParams), i, vp, u64, vp, P(u64)]
+        L.rt_scene_profile.argtypes = [vp]
         L.rt_resolve_u8.argtypes = [vp, u32, u32, u64, vp]
         L.rt_resolve_u8_device.argtypes = [vp, u32, u32, u64, vp, vp]
         L.rt_bvh_build.argtypes = [vp, u64, vp, P(C.c_double)]
@@ -197,6 +199,26 @@ class DeviceScene:
         self.lib.check(self.lib.lib.rt_trace_work(self.h, rays.ctypes.data, rays.shape[0], seed, hits.ctypes.data, work))
         w = list(work)
         return hits, {"entries": w[0], **{abi.NODE_KINDS[k]: w[1 + k] for k in range(9)}}
+
+    def profile(self):
+        """The closest-hit kernel profile rt_render runs on this scene (bits: 1 wrapped boxes in one step, 2 general
+        medium boundary walk, 4 vote exit from the box phase)."""
+        rc = self.lib.lib.rt_scene_profile(self.h)
+        if rc < 0:
+            self.lib.check(rc)
+        return rc
+
+    def path_step(self, params, rays, profile=abi.RT_PROFILE_OWN, want_work=False):
+        """rt_path_step: one bounce of the render path's own extend + shade launches on the given rays."""
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY_DTYPE)
+        out = np.zeros(rays.shape[0], dtype=abi.PATHSTEP_DTYPE)
+        work = (C.c_uint64 * 10)()
+        self.lib.check(self.lib.lib.rt_path_step(self.h, C.byref(params), profile, rays.ctypes.data, rays.shape[0], out.ctypes.data,
+                                                work if want_work else None))
+        if not want_work:
+            return out
+        w = list(work)
+        return out, {"entries": w[0], **{abi.NODE_KINDS[k]: w[1 + k] for k in range(9)}}
 
     def render(self, cam, params, accum=None, want_stats=True):
         """rt_render into a host float32 [H, W, 3] buffer (created zeroed if not given)."""

@@ -14,7 +14,7 @@ from conftest import ROOT
 from raytracer_amd import abi, lib
 
 STRUCTS = ["RtNode", "RtSphere", "RtMovingSphere", "RtRect", "RtBox6", "RtTriangle", "RtXform", "RtMedium", "RtMaterial",
-           "RtTexture", "RtPerlin", "RtImage", "RtSceneDesc", "RtRay", "RtHit", "RtHitRecord", "RtCamera", "RtRenderParams",
+           "RtTexture", "RtPerlin", "RtImage", "RtSceneDesc", "RtRay", "RtHit", "RtHitRecord", "RtPathStep", "RtCamera", "RtRenderParams",
            "RtTraceStats", "RtRenderStats", "RtSceneOptions", "RtSceneSetup"]
 
 

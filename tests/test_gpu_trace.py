@@ -147,7 +147,7 @@ def random_scene_pair(rng, rtlib, orc, n_obj):
     builders = [rtlib.host.builder(seed=seed), orc.api.builder(seed=seed)]
     roots = []
     plan = []
-    kinds = rng.integers(0, 9, size=n_obj)
+    kinds = rng.integers(0, 10, size=n_obj)
     for k in kinds:
         c = rng.uniform(-4, 4, 3)
         plan.append((int(k), c, rng.uniform(0.2, 1.2), rng.uniform(-1, 1, 3), rng.uniform(-60, 60), rng.uniform(0.05, 0.8),
@@ -173,6 +173,8 @@ def random_scene_pair(rng, rtlib, orc, n_obj):
                 o = b.constant_medium(b.sphere(c, r, mat), dens, [0.9, 0.9, 0.9])
             elif k == 7:
                 o = b.constant_medium(b.translate(b.rotate_y(b.box6(c, c + ext, mat), ang), off), dens, [0.2, 0.4, 0.9])
+            elif k == 9:  # a medium whose boundary is neither one sphere nor one wrapped box: the general boundary walk
+                o = b.constant_medium(b.translate(b.sphere(c, r, mat), off), dens, [0.7, 0.3, 0.3])
             else:  # a nested BVH of small spheres inside rotate(translate(rotate()))
                 inner = [b.sphere(c + rng_off, 0.15, mat) for rng_off in ([0, 0, 0], [0.4, 0, 0], [0, 0.4, 0], [0, 0, 0.4], [0.4, 0.4, 0])]
                 o = b.rotate_y(b.translate(b.rotate_y(b.bvh(b.list(inner)), ang), off), -ang * 0.5)

@@ -32,6 +32,49 @@ def test_oracle_reproduces_golden(orc, sid):
     if sid != 1:  # random_scene builds its BVH over t in (0, 0.1) while the shutter is (0, 1): src/main.rs:315 vs :177-178
         assert np.array_equal(hits_ref["prim_id"], hits["prim_id"])
         assert np.array_equal(hits_ref["t"].view(np.uint64), hits["t"].view(np.uint64))
+    # one ray_color iteration per ray (emitted, attenuation, scattered ray): bit for bit
+    su = orc.api.scene_setup(sid)
+    p = orc.make_params(meta["width"], meta["height"], 0, 4, list(su.background), seed=SEED)
+    steps = orc.path_step(sc, p, g["rays"], mode=oracle.AABB_TIGHT)
+    assert steps.tobytes() == g["steps"].tobytes()
+    assert np.array_equal(steps["prim_id"], hits["prim_id"]) and np.array_equal(steps["t"][hits["prim_id"] != 0xFFFFFFFF], hits["t"][hits["prim_id"] != 0xFFFFFFFF])
+    assert int(steps["scattered"].sum()) == meta["n_scattered"]
+    orc.api.scene_free(sc)
+
+
+def test_path_step_is_one_iteration_of_ray_color(orc):
+    # Chaining path steps (L += T * emitted; T *= attenuation; next ray) must reproduce the oracle's recursive
+    # ray_color (src/color.rs:34-63) on whole paths: the unrolled loop the GPU runs is the same function.
+    from raytracer_amd import abi
+    sid = 9
+    sc = orc.api.scene_build(sid, seed=SEED, **scene_kwargs(sid))
+    su = orc.api.scene_setup(sid)
+    cam = orc.api.camera(su)
+    W = H = 24
+    spp = 2
+    p = orc.make_params(W, H, 0, spp, list(su.background), seed=SEED, max_depth=12)
+    want, _, _ = orc.render(sc, cam, p, mode=oracle.AABB_TIGHT, threads=2)
+    rays = orc.harvest(sc, cam, p, n_paths=W * H * spp, max_rays=W * H * spp, max_bounce=0)
+    assert len(rays) == W * H * spp
+    L = np.zeros((len(rays), 3))
+    T = np.ones((len(rays), 3))
+    alive = np.arange(len(rays))
+    cur = rays.copy()
+    for bounce in range(12):
+        cur["bounce"] = bounce
+        st = orc.path_step(sc, p, cur, mode=oracle.AABB_TIGHT)
+        L[alive] += T[alive] * st["emitted"]
+        go = st["scattered"] == 1
+        T[alive[go]] *= st["attenuation"][go]
+        nxt = cur[go].copy()
+        nxt["o"], nxt["d"] = st["o"][go], st["d"][go]
+        alive, cur = alive[go], nxt
+        if not len(alive):
+            break
+    got = np.zeros((H, W, 3))
+    np.add.at(got.reshape(-1, 3), rays["pixel"], L)
+    # emitted + att * (emitted' + att' * ...) vs sum of T * emitted: the same terms associated differently
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-13)
     orc.api.scene_free(sc)
 
 

@@ -1,7 +1,7 @@
 """Generates the committed golden vectors under tests/golden/ with the CPU oracle:
 per scene ~4096 rays (primary rays and their bounce 1..3 continuations harvested from
-oracle path samples) with the oracle's closest hit (prim_id, sub, raw bits of t) and full
-hit record. The reference itself holds no vectors for this path (its tests cover Vec3
+oracle path samples) with the oracle's closest hit (prim_id, sub, raw bits of t), full
+hit record, and the outcome of one ray_color iteration on it (emitted, attenuation, scattered ray). The reference itself holds no vectors for this path (its tests cover Vec3
 operators only), so these pin the oracle against its own regressions and give the GPU
 tests a fixed ray set; they are not outputs of the Rust binary.
 
@@ -45,10 +45,12 @@ def main():
         rays = o.harvest(sc, cam, p, n_paths=3000, max_rays=4096, max_bounce=3)
         hits, recs, stats = o.trace(sc, rays, seed=SEED, mode=oracle.AABB_TIGHT, records=True)
         hits_ref, _, stats_ref = o.trace(sc, rays, seed=SEED, mode=oracle.AABB_REFERENCE)
+        steps = o.path_step(sc, p, rays, mode=oracle.AABB_TIGHT)  # emitted / attenuation / scattered ray of each ray
         np.savez_compressed(os.path.join(OUT, "trace_scene%02d.npz" % sid), rays=rays, hits=hits, records=recs,
-                            hits_reference_aabb=hits_ref)
+                            hits_reference_aabb=hits_ref, steps=steps)
         meta["scenes"][str(sid)] = {
             "options": {k: v for k, v in opt.items()}, "width": W, "height": H, "n_rays": int(len(rays)),
+            "n_scattered": int(steps["scattered"].sum()), "n_emitting": int((steps["emitted"] != 0).any(axis=1).sum()),
             "n_hits": int((hits["prim_id"] != 0xFFFFFFFF).sum()),
             "box_tests_tight": int(stats["box_tests"]), "box_tests_reference": int(stats_ref["box_tests"]),
             "ids_differ_tight_vs_reference": int((hits["prim_id"] != hits_ref["prim_id"]).sum()),
