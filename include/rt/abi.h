@@ -284,6 +284,13 @@ int rt_resolve_u8_device(const float* accum_rgb_dev, uint32_t width, uint32_t he
  * or without a finite centre are refused (RT_E_INVALID). `ms_device`, when not
  * NULL, receives the device time of the build without the copies. */
 int rt_bvh_build(const double* boxes, uint64_t n, RtNode* tokens_out, double* ms_device);
+/* The same tree (src/bvh.rs:17-98 stand-in) with boxes and tokens resident on the current HIP device: boxes_dev =
+ * n x 6 doubles, tokens_dev = room for 2 n - 1 tokens; nothing crosses PCIe. The work is enqueued on `stream`
+ * (a hipStream_t, NULL = default stream); the call returns once it has completed, because the scratch memory it
+ * allocates for the build (about 200 bytes per object) is released on return. `flag_dev`, when not NULL, is a
+ * device word that receives 1 if some box holds NaN or has no finite centre (the tokens are then well-formed but
+ * meaningless) and 0 otherwise. */
+int rt_bvh_build_device(const double* boxes_dev, uint64_t n, RtNode* tokens_dev, uint32_t* flag_dev, void* stream, double* ms_device);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -286,23 +287,52 @@ __global__ __launch_bounds__(BLOCK) void k_tokens(Tree t, const double* __restri
     tokens[pos] = out;
 }
 
-struct DeviceBuffers {  // freed on every way out
-    void* p[16] = {};
-    int used = 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    ~DeviceBuffers() {
-        for (int i = 0; i < used; ++i) (void)hipFree(p[i]);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-    }
-    template <class T>
-    hipError_t get(T** out, uint64_t count) {
-        void* q = nullptr;
-        const hipError_t e = hipMalloc(&q, count * sizeof(T) + 16);
-        if (e == hipSuccess) { p[used++] = q; *out = (T*)q; }
-        return e;
-    }
+// Scratch memory of one build, carved out of one block: every array starts on a 256-byte boundary.
+struct Scratch {
+    double *partial, *bounds, *from_start, *to_end, *table;
+    uint64_t *code_in, *code;
+    uint32_t *obj_in, *obj, *parent_inner, *parent_leaf, *first, *last, *split, *bad;
+    char* sort;
+    size_t sort_bytes, total;
+    uint32_t reduce_blocks, blocks, levels;
 };
+
+inline size_t align256(size_t b) { return (b + 255u) & ~(size_t)255u; }
+
+// Lays the arrays of a build over n objects out from `base` (which may be null: then only `total` is of use).
+inline Scratch carve(char* base, uint32_t n, size_t sort_bytes) {
+    Scratch s{};
+    s.reduce_blocks = (uint32_t)std::min<uint64_t>(1024, ((uint64_t)n + BLOCK - 1) / BLOCK);
+    s.blocks = (n + RANGE - 1u) / RANGE;
+    s.levels = 1;
+    while ((2u << (s.levels - 1)) <= s.blocks) ++s.levels;  // levels - 1 = floor(log2(blocks))
+    s.sort_bytes = sort_bytes;
+    size_t off = 0;
+    auto take = [&](auto** out, size_t count) {
+        using T = std::remove_pointer_t<std::remove_pointer_t<decltype(out)>>;
+        *out = reinterpret_cast<T*>(base + off);
+        off += align256(count * sizeof(T) + 16);
+    };
+    const size_t inner = n - 1;
+    take(&s.partial, 6ull * s.reduce_blocks);
+    take(&s.bounds, 6);
+    take(&s.bad, 1);
+    take(&s.code_in, n);
+    take(&s.code, n);
+    take(&s.obj_in, n);
+    take(&s.obj, n);
+    take(&s.parent_inner, inner);
+    take(&s.parent_leaf, n);
+    take(&s.first, inner);
+    take(&s.last, inner);
+    take(&s.split, inner);
+    take(&s.from_start, 6ull * n);
+    take(&s.to_end, 6ull * n);
+    take(&s.table, 6ull * s.blocks * s.levels);
+    take(&s.sort, sort_bytes);
+    s.total = off;
+    return s;
+}
 
 }  // namespace bvh
 
@@ -316,77 +346,120 @@ struct DeviceBuffers {  // freed on every way out
         }                                                                                                  \
     } while (0)
 
-extern "C" int rt_bvh_build(const double* boxes, uint64_t n64, RtNode* tokens_out, double* ms_device) {
-    using namespace bvh;
-    if (!boxes || !tokens_out) return rt::set_error(RT_E_INVALID, "null argument");
+namespace bvh {
+
+int check_count(uint64_t n64) {
     if (n64 < 2) return rt::set_error(RT_E_INVALID, "a tree needs at least two objects");
     if (n64 > RT_BVH_MAX_OBJECTS) return rt::set_error(RT_E_INVALID, "too many objects for one tree");
+    return RT_OK;
+}
+
+int sort_temp_bytes(uint32_t n, size_t* bytes) {
+    *bytes = 0;
+    BVH_TRY(rocprim::radix_sort_pairs(nullptr, *bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                      (size_t)n, 0u, 63u, (hipStream_t) nullptr));
+    return RT_OK;
+}
+
+// The build proper: everything is enqueued on `stream`, nothing is allocated and nothing waits. d_flag (may be
+// null) receives 1 when a box holds NaN or has no finite centre.
+int enqueue_build(const double* d_boxes, uint32_t n, RtNode* d_tokens, uint32_t* d_flag, const Scratch& m, hipStream_t stream) {
+    const uint32_t inner = n - 1;
+    BVH_TRY(hipMemsetAsync(m.bad, 0, sizeof(uint32_t), stream));
+    const uint32_t per_leaf = (n + BLOCK - 1) / BLOCK, per_inner = (inner + BLOCK - 1) / BLOCK;
+    const uint32_t per_node = (uint32_t)((2ull * n - 1 + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_centre_bounds, dim3(m.reduce_blocks), dim3(BLOCK), 0, stream, d_boxes, n, m.partial, m.bad);
+    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(BLOCK), 0, stream, m.partial, m.reduce_blocks, m.bounds);
+    hipLaunchKernelGGL(k_morton, dim3(per_leaf), dim3(BLOCK), 0, stream, d_boxes, n, m.bounds, m.code_in, m.obj_in);
+    BVH_TRY(hipGetLastError());
+    size_t sort_bytes = m.sort_bytes;
+    BVH_TRY(rocprim::radix_sort_pairs(m.sort, sort_bytes, m.code_in, m.code, m.obj_in, m.obj, (size_t)n, 0u, 63u, stream));
+    Tree t{m.code, m.obj, m.parent_inner, m.parent_leaf, m.first, m.last, m.split, m.from_start, m.to_end, m.table, n, m.blocks};
+    hipLaunchKernelGGL(k_radix_tree, dim3(per_inner), dim3(BLOCK), 0, stream, t);
+    hipLaunchKernelGGL(k_block_unions, dim3(per_leaf), dim3(BLOCK), 0, stream, t, d_boxes);
+    for (uint32_t k = 1; k < m.levels; ++k)
+        hipLaunchKernelGGL(k_table_level, dim3((m.blocks + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, t, k);
+    hipLaunchKernelGGL(k_tokens, dim3(per_node), dim3(BLOCK), 0, stream, t, d_boxes, d_tokens);
+    BVH_TRY(hipGetLastError());
+    if (d_flag) BVH_TRY(hipMemcpyAsync(d_flag, m.bad, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+    return RT_OK;
+}
+
+struct DeviceBuffers {  // freed on every way out
+    void* p[4] = {};
+    int used = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~DeviceBuffers() {
+        for (int i = 0; i < used; ++i) (void)hipFree(p[i]);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    hipError_t get(void** out, size_t bytes) {
+        void* q = nullptr;
+        const hipError_t e = hipMalloc(&q, bytes + 16);
+        if (e == hipSuccess) { p[used++] = q; *out = q; }
+        return e;
+    }
+};
+
+int need_device() {
     int device_count = 0;
     if (hipGetDeviceCount(&device_count) != hipSuccess || device_count < 1) {
         (void)hipGetLastError();
         return rt::set_error(RT_E_DEVICE, "building a tree on the device needs a HIP device; there is no CPU path");
     }
+    return RT_OK;
+}
+
+}  // namespace bvh
+
+extern "C" int rt_bvh_build_device(const double* boxes_dev, uint64_t n64, RtNode* tokens_dev, uint32_t* flag_dev, void* stream,
+                                   double* ms_device) {
+    using namespace bvh;
+    if (!boxes_dev || !tokens_dev) return rt::set_error(RT_E_INVALID, "null argument");
+    if (int rc = check_count(n64)) return rc;
+    if (int rc = need_device()) return rc;
     const uint32_t n = (uint32_t)n64;
-    const uint32_t inner = n - 1;
-    DeviceBuffers mem;
-    double *d_boxes, *d_partial, *d_bounds, *d_from_start, *d_to_end, *d_table;
-    uint64_t *d_code_in, *d_code;
-    uint32_t *d_obj_in, *d_obj, *d_parent_inner, *d_parent_leaf, *d_first, *d_last, *d_split, *d_bad;
-    RtNode* d_tokens;
-    const uint32_t reduce_blocks = (uint32_t)std::min<uint64_t>(1024, (n64 + BLOCK - 1) / BLOCK);
-    const uint32_t blocks = (n + RANGE - 1u) / RANGE;
-    uint32_t levels = 1;
-    while ((2u << (levels - 1)) <= blocks) ++levels;  // levels - 1 = floor(log2(blocks))
-    BVH_TRY(mem.get(&d_boxes, 6ull * n));
-    BVH_TRY(mem.get(&d_partial, 6ull * reduce_blocks + 6 + 2));
-    BVH_TRY(mem.get(&d_code_in, n));
-    BVH_TRY(mem.get(&d_code, n));
-    BVH_TRY(mem.get(&d_obj_in, n));
-    BVH_TRY(mem.get(&d_obj, n));
-    BVH_TRY(mem.get(&d_parent_inner, inner));
-    BVH_TRY(mem.get(&d_parent_leaf, n));
-    BVH_TRY(mem.get(&d_first, 3ull * inner));
-    BVH_TRY(mem.get(&d_from_start, 6ull * n));
-    BVH_TRY(mem.get(&d_to_end, 6ull * n));
-    BVH_TRY(mem.get(&d_table, 6ull * blocks * levels));
-    BVH_TRY(mem.get(&d_tokens, 2ull * n - 1));
-    d_bounds = d_partial + 6ull * reduce_blocks;
-    d_bad = (uint32_t*)(d_bounds + 6);
-    d_last = d_first + inner;
-    d_split = d_last + inner;
     size_t sort_bytes = 0;
-    BVH_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, d_code_in, d_code, d_obj_in, d_obj, (size_t)n, 0u, 63u, (hipStream_t) nullptr));
-    char* d_sort;
-    BVH_TRY(mem.get(&d_sort, sort_bytes));
+    if (int rc = sort_temp_bytes(n, &sort_bytes)) return rc;
+    Scratch m = carve(nullptr, n, sort_bytes);
+    DeviceBuffers mem;
+    void* base = nullptr;
+    BVH_TRY(mem.get(&base, m.total));
+    m = carve(static_cast<char*>(base), n, sort_bytes);
     BVH_TRY(hipEventCreate(&mem.e0));
     BVH_TRY(hipEventCreate(&mem.e1));
-
-    BVH_TRY(hipMemcpy(d_boxes, boxes, 6ull * n * sizeof(double), hipMemcpyHostToDevice));
-    BVH_TRY(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), nullptr));
-    BVH_TRY(hipEventRecord(mem.e0, nullptr));
-    const uint32_t per_leaf = (n + BLOCK - 1) / BLOCK, per_inner = (inner + BLOCK - 1) / BLOCK;
-    const uint32_t per_node = (uint32_t)((2ull * n - 1 + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(k_centre_bounds, dim3(reduce_blocks), dim3(BLOCK), 0, nullptr, d_boxes, n, d_partial, d_bad);
-    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(BLOCK), 0, nullptr, d_partial, reduce_blocks, d_bounds);
-    hipLaunchKernelGGL(k_morton, dim3(per_leaf), dim3(BLOCK), 0, nullptr, d_boxes, n, d_bounds, d_code_in, d_obj_in);
-    BVH_TRY(hipGetLastError());
-    BVH_TRY(rocprim::radix_sort_pairs(d_sort, sort_bytes, d_code_in, d_code, d_obj_in, d_obj, (size_t)n, 0u, 63u, (hipStream_t) nullptr));
-    Tree t{d_code, d_obj, d_parent_inner, d_parent_leaf, d_first, d_last, d_split, d_from_start, d_to_end, d_table, n, blocks};
-    hipLaunchKernelGGL(k_radix_tree, dim3(per_inner), dim3(BLOCK), 0, nullptr, t);
-    hipLaunchKernelGGL(k_block_unions, dim3(per_leaf), dim3(BLOCK), 0, nullptr, t, d_boxes);
-    for (uint32_t k = 1; k < levels; ++k)
-        hipLaunchKernelGGL(k_table_level, dim3((blocks + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, nullptr, t, k);
-    hipLaunchKernelGGL(k_tokens, dim3(per_node), dim3(BLOCK), 0, nullptr, t, d_boxes, d_tokens);
-    BVH_TRY(hipGetLastError());
-    BVH_TRY(hipEventRecord(mem.e1, nullptr));
-    uint32_t bad = 0;
-    BVH_TRY(hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost));
-    if (bad) return rt::set_error(RT_E_INVALID, "a bounding box holds NaN or has no finite centre");
-    BVH_TRY(hipMemcpy(tokens_out, d_tokens, (2ull * n - 1) * sizeof(RtNode), hipMemcpyDeviceToHost));
+    hipStream_t st = (hipStream_t)stream;
+    BVH_TRY(hipEventRecord(mem.e0, st));
+    if (int rc = enqueue_build(boxes_dev, n, tokens_dev, flag_dev, m, st)) return rc;
+    BVH_TRY(hipEventRecord(mem.e1, st));
+    BVH_TRY(hipStreamSynchronize(st));  // the scratch memory is released on return
     if (ms_device) {
         float ms = 0.0f;
         BVH_TRY(hipEventElapsedTime(&ms, mem.e0, mem.e1));
         *ms_device = ms;
     }
+    return RT_OK;
+}
+
+extern "C" int rt_bvh_build(const double* boxes, uint64_t n64, RtNode* tokens_out, double* ms_device) {
+    using namespace bvh;
+    if (!boxes || !tokens_out) return rt::set_error(RT_E_INVALID, "null argument");
+    if (int rc = check_count(n64)) return rc;
+    if (int rc = need_device()) return rc;
+    const uint32_t n = (uint32_t)n64;
+    DeviceBuffers mem;
+    void *d_boxes = nullptr, *d_tokens = nullptr, *d_flag = nullptr;
+    BVH_TRY(mem.get(&d_boxes, 6ull * n * sizeof(double)));
+    BVH_TRY(mem.get(&d_tokens, (2ull * n - 1) * sizeof(RtNode)));
+    BVH_TRY(mem.get(&d_flag, sizeof(uint32_t)));
+    BVH_TRY(hipMemcpy(d_boxes, boxes, 6ull * n * sizeof(double), hipMemcpyHostToDevice));
+    if (int rc = rt_bvh_build_device(static_cast<const double*>(d_boxes), n64, static_cast<RtNode*>(d_tokens), static_cast<uint32_t*>(d_flag),
+                                     nullptr, ms_device))
+        return rc;
+    uint32_t bad = 0;
+    BVH_TRY(hipMemcpy(&bad, d_flag, sizeof(bad), hipMemcpyDeviceToHost));
+    if (bad) return rt::set_error(RT_E_INVALID, "a bounding box holds NaN or has no finite centre");
+    BVH_TRY(hipMemcpy(tokens_out, d_tokens, (2ull * n - 1) * sizeof(RtNode), hipMemcpyDeviceToHost));
     return RT_OK;
 }

@@ -127,3 +127,45 @@ def test_builder_call(gpu, orc):
     ds.close()
     hs.close()
     orc.api.scene_free(osc)
+
+
+def build_on_device(gpu, boxes, entry="rt_bvh_build_device", stream=None):
+    """Calls a device-resident tree build through the C ABI with torch-owned device buffers."""
+    import ctypes as C
+    import torch
+    n = boxes.shape[0]
+    d_boxes = torch.from_numpy(np.ascontiguousarray(boxes, dtype=np.float64)).cuda()
+    d_tokens = torch.zeros((2 * n - 1) * abi.NODE_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    d_flag = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+    fn = getattr(gpu.lib, entry)
+    args = [d_boxes.data_ptr(), n, d_tokens.data_ptr(), d_flag.data_ptr(), stream.cuda_stream if stream is not None else None]
+    if entry == "rt_bvh_build_device":
+        ms = C.c_double(0.0)
+        args.append(C.byref(ms))
+    gpu.check(fn(*args))
+    if stream is not None:
+        stream.synchronize()
+    else:
+        torch.cuda.synchronize()
+    return d_tokens.cpu().numpy().view(abi.NODE_DTYPE), int(d_flag.item())
+
+
+@pytest.mark.parametrize("n", [2, 3, 64, 4097, 250_000])
+def test_device_resident_build_equals_the_host_buffer_build(gpu, orc, n):
+    import torch
+    rng = np.random.default_rng(n)
+    c = rng.normal(0.0, 5.0, (n, 3))
+    h = rng.uniform(0.0, 0.3, (n, 3))
+    boxes = np.concatenate([c - h, c + h], axis=1)
+    want, _ = gpu.bvh_build(boxes)
+    got, flag = build_on_device(gpu, boxes)
+    assert same_tokens(got, want) and flag == 0
+    assert same_tokens(got, orc.lbvh_tokens(boxes))
+    s = torch.cuda.Stream()
+    got2, flag2 = build_on_device(gpu, boxes, stream=s)
+    assert same_tokens(got2, want) and flag2 == 0
+    if n >= 3:
+        bad = boxes.copy()
+        bad[1, 4] = np.nan
+        _, flag3 = build_on_device(gpu, bad)
+        assert flag3 == 1
