@@ -292,6 +292,18 @@ int rt_bvh_build(const double* boxes, uint64_t n, RtNode* tokens_out, double* ms
  * meaningless) and 0 otherwise. */
 int rt_bvh_build_device(const double* boxes_dev, uint64_t n, RtNode* tokens_dev, uint32_t* flag_dev, void* stream, double* ms_device);
 
+#define RT_BVH_NOALLOC_MAX_OBJECTS 65536u
+#define RT_BVH_NOALLOC_SCRATCH_BYTES (16u << 20)
+/* rt_bvh_build_device for callers that cannot allocate: code under HIP graph capture, tight per-frame rebuild
+ * loops, harnesses that forbid hipMalloc. It has no counterpart in the reference. Same arguments and same tokens
+ * as rt_bvh_build_device, but it allocates nothing, neither device nor host memory, and does not wait: the work
+ * is enqueued on `stream` and the call returns. The scratch memory of the build (sort keys, tree links, range
+ * unions) lives in a static device array of RT_BVH_NOALLOC_SCRATCH_BYTES that each GPU the library runs on holds
+ * until the process ends; n is limited to RT_BVH_NOALLOC_MAX_OBJECTS (RT_E_INVALID with a message beyond it).
+ * All calls on one GPU share that array: two calls whose work overlaps in time on one GPU (different streams,
+ * different threads) race; order them on one stream or with events. */
+int rt_bvh_build_device_noalloc(const double* boxes_dev, uint64_t n, RtNode* tokens_dev, uint32_t* flag_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

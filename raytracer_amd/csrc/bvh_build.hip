@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 
@@ -440,6 +441,54 @@ extern "C" int rt_bvh_build_device(const double* boxes_dev, uint64_t n64, RtNode
         *ms_device = ms;
     }
     return RT_OK;
+}
+
+// ---- the build without any allocation -----------------------------------------------------------------------
+// Scratch memory of rt_bvh_build_device_noalloc: one array per GPU the library runs on, held until the process ends.
+// In host code the array's name is only a stand-in for the symbol; its device address on the current GPU comes from
+// hipGetSymbolAddress, once per device, and is what every kernel argument and memset below uses.
+static __device__ __align__(256) unsigned char scratch[RT_BVH_NOALLOC_SCRATCH_BYTES];
+
+namespace bvh {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+char* g_scratch_ptr[MAX_DEVICES] = {};  // device address of `scratch` on each GPU, looked up on first use
+
+int scratch_on_current_device(char** out) {
+    int dev = -1;
+    BVH_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return rt::set_error(RT_E_UNSUPPORTED, "device ordinal beyond the scratch table");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        BVH_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return rt::set_error(RT_E_DEVICE, "hipGetSymbolAddress returned a null address for the scratch array");
+        g_scratch_ptr[dev] = static_cast<char*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return RT_OK;
+}
+}  // namespace bvh
+
+extern "C" int rt_bvh_build_device_noalloc(const double* boxes_dev, uint64_t n64, RtNode* tokens_dev, uint32_t* flag_dev, void* stream) {
+    using namespace bvh;
+    if (!boxes_dev || !tokens_dev) return rt::set_error(RT_E_INVALID, "null argument");
+    if (n64 < 2) return rt::set_error(RT_E_INVALID, "a tree needs at least two objects");
+    if (n64 > RT_BVH_NOALLOC_MAX_OBJECTS)
+        return rt::set_error(RT_E_INVALID, "rt_bvh_build_device_noalloc handles at most " + std::to_string(RT_BVH_NOALLOC_MAX_OBJECTS) +
+                                               " objects (" + std::to_string(n64) + " given); use rt_bvh_build_device");
+    const uint32_t n = (uint32_t)n64;
+    size_t sort_bytes = 0;
+    if (int rc = sort_temp_bytes(n, &sort_bytes)) return rc;  // a size query: nothing is allocated or launched
+    const size_t need = carve(nullptr, n, sort_bytes).total;
+    if (need > (size_t)RT_BVH_NOALLOC_SCRATCH_BYTES)
+        return rt::set_error(RT_E_INVALID, "the build needs " + std::to_string(need) + " bytes of scratch memory, the static area holds " +
+                                               std::to_string((size_t)RT_BVH_NOALLOC_SCRATCH_BYTES));
+    char* base = nullptr;
+    if (int rc = scratch_on_current_device(&base)) return rc;
+    // every array of the build is written in full before it is read, except the flag word, which enqueue_build clears;
+    // what an earlier call left behind beyond this call's n is never read
+    return enqueue_build(boxes_dev, n, tokens_dev, flag_dev, carve(base, n, sort_bytes), (hipStream_t)stream);
 }
 
 extern "C" int rt_bvh_build(const double* boxes, uint64_t n64, RtNode* tokens_out, double* ms_device) {

@@ -19,7 +19,7 @@ ABI_SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_trace_closest",
     "rt_trace_records", "rt_trace_closest_device", "rt_trace_work", "rt_render", "rt_render_device", "rt_render_work",
     "rt_path_step", "rt_scene_profile", "rt_resolve_u8",
-    "rt_resolve_u8_device", "rt_bvh_build", "rt_bvh_build_device",
+    "rt_resolve_u8_device", "rt_bvh_build", "rt_bvh_build_device", "rt_bvh_build_device_noalloc",
 )
 HOST_SYMBOLS = (
     "rth_scene_build", "rth_scene_desc", "rth_scene_setup", "rth_scene_free", "rth_camera_new", "rth_builder_new",
@@ -88,6 +88,7 @@ class Library:
         L.rt_resolve_u8_device.argtypes = [vp, u32, u32, u64, vp, vp]
         L.rt_bvh_build.argtypes = [vp, u64, vp, P(C.c_double)]
         L.rt_bvh_build_device.argtypes = [vp, u64, vp, vp, vp, P(C.c_double)]
+        L.rt_bvh_build_device_noalloc.argtypes = [vp, u64, vp, vp, vp]
         for name in ABI_SYMBOLS:
             f = getattr(L, name)
             if name not in ("rt_last_error", "rt_abi_version", "rt_scene_destroy"):
