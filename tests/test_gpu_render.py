@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import CONFIG_SCENES, SEED, scene_kwargs
+from conftest import CONFIG_SCENES, SCENE_OPTS, SEED, scene_kwargs
 from raytracer_amd import abi, lib
 
 pytestmark = pytest.mark.gpu
@@ -27,11 +27,19 @@ def resolved(acc, spp):
     return np.sqrt(np.asarray(acc, dtype=np.float64) / spp)  # un-quantised display values, src/main.rs:216-219
 
 
-@pytest.mark.parametrize("sid", CONFIG_SCENES)
+# Pixels whose accumulated value may differ from the oracle's by more than PIXEL_RTOL: a path leaves the oracle's
+# only where a last-bit difference of sin / cos / atan2 / asin / log10 flips a decision (a checker cell, a texel, a
+# medium hit); everywhere else the two follow the same paths and differ by the f32 rounding of the accumulator.
+PIXEL_RTOL = 1e-6
+PIXEL_FRACTION = 0.002
+
+
+@pytest.mark.parametrize("sid", sorted(SCENE_OPTS))
 def test_image_rmse_vs_oracle(gpu, orc, sid):
-    # Tolerance: RMSE(GPU, oracle) on resolved [0,1] values must stay below 1.5 x the RMSE between two oracle
-    # renders that differ only in the RNG seed (the noise floor at this sample count); in practice the GPU follows
-    # the oracle's paths and lands orders of magnitude below it.
+    # Two bars. The north-star one: RMSE(GPU, oracle) on resolved [0,1] values below 1.5 x the RMSE between two
+    # oracle renders that differ only in the RNG seed (the noise floor at this sample count). The one the path
+    # actually achieves: the GPU follows the oracle path for path, so all but PIXEL_FRACTION of the pixels agree
+    # to PIXEL_RTOL relative and the RMSE lies five orders of magnitude below the noise.
     hs, ds, osc, su, cam = setup_pair(gpu, orc, sid)
     W = 72
     H = int(W / su.aspect_ratio)
@@ -46,6 +54,11 @@ def test_image_rmse_vs_oracle(gpu, orc, sid):
     rmse = float(np.sqrt(np.mean((a - b) ** 2)))
     assert noise > 0
     assert rmse <= 1.5 * noise, (rmse, noise)
+    off = np.abs(acc_g - acc_o) > PIXEL_RTOL * np.abs(acc_o) + 1e-9
+    frac = float(off.any(axis=2).mean())
+    assert frac <= PIXEL_FRACTION, (frac, rmse, noise)
+    assert rmse <= 1e-3 * noise + 1e-7 or frac > 0, (rmse, noise)
+    print("scene %d: rmse %.3g, noise %.3g, pixels off %.4f" % (sid, rmse, noise, frac))
     assert st.paths == W * H * spp
     assert abs(int(st.rays) - ost["rays"]) <= 0.005 * ost["rays"], (st.rays, ost["rays"])
     assert np.isfinite(acc_g).all() and (acc_g >= 0).all()
@@ -137,7 +150,7 @@ FULL = {1: (1200, 800), 7: (600, 600), 8: (600, 600), 9: (800, 800)}
 @pytest.mark.parametrize("sid", sorted(FULL))
 def test_full_resolution_properties(gpu, orc, sid):
     # BASELINE image sizes, few samples: additivity over sample ranges, exact repeatability, finite non-negative
-    # radiance, every path issues at least one query, and the image mean agrees with a low-resolution oracle render.
+    # radiance, every path issues at least one query, and one sample per pixel equal to the oracle's at the same size.
     hs, ds, osc, su, cam = setup_pair(gpu, orc, sid)
     W, H = FULL[sid]
     bg = list(su.background)
@@ -147,9 +160,11 @@ def test_full_resolution_properties(gpu, orc, sid):
     assert np.allclose(a + b, both, rtol=2e-6, atol=1e-6)
     assert sa.rays + sb.rays == sab.rays and sab.paths == W * H * 4 and sab.rays >= sab.paths
     assert np.isfinite(both).all() and (both >= 0).all()
-    small = orc.render(osc, cam, lib.make_params(W // 10, H // 10, 0, 16, bg), mode=oracle.AABB_TIGHT, threads=8)[0]
-    m_gpu, m_orc = both.mean() / 4, small.mean() / 16
-    assert abs(m_gpu - m_orc) <= 0.12 * m_orc + 1e-3, (m_gpu, m_orc)
+    # the first sample of every pixel against the oracle at the full image size, pixel for pixel
+    one, _ = ds.render(cam, lib.make_params(W, H, 0, 1, bg))
+    want = orc.render(osc, cam, lib.make_params(W, H, 0, 1, bg), mode=oracle.AABB_TIGHT, threads=8)[0]
+    off = np.abs(one - want) > PIXEL_RTOL * np.abs(want) + 1e-9
+    assert off.any(axis=2).mean() <= PIXEL_FRACTION, off.any(axis=2).mean()
     ds.close(); hs.close(); orc.api.scene_free(osc)
 
 
