@@ -244,3 +244,57 @@ def test_box_bounded_media_follow_the_oracle_path_for_path(gpu, orc):
         assert abs(work[mine] - ost[theirs]) <= 0.004 * ost[theirs], (mine, work[mine], ost[theirs])
     assert abs(work["rect"] - (ost["rect"] - 6 * ost["box6"])) <= 0.004 * ost["rect"]
     ds.close(); hs.close(); orc.api.scene_free(osc)
+
+
+def test_c5_ten_million_triangles_at_4k(gpu, orc):
+    # BASELINE configs[4] at its stated size: the kaleidoscope with 10 M synthetic triangles (21.7 M stream entries,
+    # 1.5 GB of tables, nothing staged in LDS), tree built on the device, 3840 x 2160. Size-independent properties
+    # (additivity over sample ranges, repeatability, finite non-negative radiance, one query per path at least) and,
+    # against the oracle building the same tree on the CPU: closest hits of ~20 000 harvested rays id for id through
+    # the stand-alone query and through the render kernels' own bounce, and the first sample of every pixel.
+    import time
+    n_tri = 10_000_000
+    t0 = time.time()
+    hs = lib.HostScene.build(12, seed=SEED, flags=abi.RT_SCENE_BVH_LBVH, n_triangles=n_tri)
+    t_host = time.time() - t0
+    assert hs.desc.n_triangles >= n_tri and hs.desc.n_nodes > 2 * n_tri
+    ds = lib.DeviceScene(hs)
+    su = gpu.host.scene_setup(12)
+    su.aspect_ratio = 3840 / 2160
+    cam = gpu.host.camera(su)
+    W, H = 3840, 2160
+    bg = list(su.background)
+    a, sa = ds.render(cam, lib.make_params(W, H, 0, 2, bg))
+    b, sb = ds.render(cam, lib.make_params(W, H, 2, 4, bg))
+    both, sab = ds.render(cam, lib.make_params(W, H, 0, 4, bg))
+    again, _ = ds.render(cam, lib.make_params(W, H, 0, 4, bg))
+    assert np.array_equal(both, again)
+    assert np.allclose(a + b, both, rtol=2e-6, atol=1e-6)
+    assert sa.rays + sb.rays == sab.rays and sab.paths == W * H * 4 and sab.rays >= sab.paths
+    assert np.isfinite(both).all() and (both >= 0).all()
+    t0 = time.time()
+    osc = orc.api.scene_build(12, seed=SEED, flags=abi.RT_SCENE_BVH_LBVH, n_triangles=n_tri)
+    t_orc = time.time() - t0
+    p = orc.make_params(W, H, 0, 2, bg, seed=SEED)
+    rays = orc.harvest(osc, cam, p, n_paths=12000, max_rays=1 << 15, max_bounce=3)
+    assert len(rays) > 15000
+    oh, _, ost = orc.trace(osc, rays, seed=SEED, mode=oracle.AABB_TIGHT)
+    gh, work = ds.trace_work(rays, seed=SEED)
+    assert np.array_equal(oh["prim_id"], gh["prim_id"]) and np.array_equal(oh["sub"], gh["sub"])
+    hit = oh["prim_id"] != abi.RT_MISS
+    assert np.array_equal(oh["t"][hit].view(np.uint64), gh["t"][hit].view(np.uint64))
+    assert work["inner"] == ost["box_tests"] and work["triangle"] == ost["triangle"] and work["box6"] == ost["box6"]
+    want = orc.path_step(osc, p, rays, mode=oracle.AABB_TIGHT)
+    got, work2 = ds.path_step(p, rays, want_work=True)
+    assert np.array_equal(want["prim_id"], got["prim_id"]) and np.array_equal(want["sub"], got["sub"])
+    assert np.array_equal(want["t"].view(np.uint64), got["t"].view(np.uint64))
+    assert np.array_equal(want["scattered"], got["scattered"]) and np.array_equal(want["attenuation"], got["attenuation"])
+    assert np.abs(want["d"] - got["d"]).max() <= 1e-15 * max(1.0, np.abs(want["d"]).max())
+    assert work2["inner"] == ost["box_tests"] and work2["triangle"] == ost["triangle"]
+    # the first sample of all 8.3 M pixels against the oracle, pixel for pixel
+    one, _ = ds.render(cam, lib.make_params(W, H, 0, 1, bg))
+    rows = orc.render(osc, cam, lib.make_params(W, H, 0, 1, bg), mode=oracle.AABB_TIGHT, threads=16)[0]
+    off = np.abs(one - rows) > PIXEL_RTOL * np.abs(rows) + 1e-9
+    assert off.any(axis=2).mean() <= PIXEL_FRACTION, off.any(axis=2).mean()
+    print("C5 full size: host scene %.1f s, oracle scene %.1f s, %d rays per 4-spp render" % (t_host, t_orc, sab.rays))
+    ds.close(); hs.close(); orc.api.scene_free(osc)
