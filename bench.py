@@ -12,6 +12,14 @@ tables, path state and image never leave HBM inside the timed region. With N > 1
 torch.distributed over RCCL) every rank renders its own sample range of every pixel (weak scaling: per-GPU
 work per step is fixed) and one all-reduce of the float accumulation buffers closes the timed region.
 
+`--scaling strong --spp T` renders a fixed job instead (T samples of every pixel in all, BASELINE configs[2] and [3]
+are stated this way): a step is the whole job, rank r renders its share of the T samples in equal batches (no
+runt batch), so per-GPU work shrinks as N grows.
+
+Started without torch.distributed.run (no WORLD_SIZE in the environment) with --gpus N > 1, the script starts the N
+ranks itself: it launches `python -m torch.distributed.run --nproc-per-node N` on this file as a child process, before
+anything in this process has touched the GPU, relays the child's output and exits with its code.
+
 Rank 0 prints one JSON line: whole-job samples/s, the roofline of the dominant kernel (extend: BVH closest
 hit) from HIP-event timings taken inside the timed region and algorithmic bytes counted by an instrumented
 pass outside it, and the CPU oracle timed on the host cores on a bounded sample of the same workload."""
@@ -31,7 +39,14 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from raytracer_amd import abi, assets, lib  # noqa: E402
-from raytracer_amd.distributed import allreduce_accum  # noqa: E402
+from raytracer_amd.distributed import allreduce_accum, equal_batches, shard_samples  # noqa: E402
+
+F64_PEAK_TFLOPS = 78.6  # MI355X vector f64 peak (FMA counted as two)
+# Algorithmic f64 operations of the closest-hit walk, per visit: a box test is 6 fma + 6 max / min + the compare; the
+# primitive tests as the reference writes them (sphere src/hittable.rs:72-113, rect src/aarect.rs:30-48, a box of six
+# sides = 6 rects, triangle src/triangle.rs:26-69); wrappers rotate / translate the ray; a medium adds sqrt, log10
+# and the interval arithmetic of src/constant_medium.rs:52-73.
+FLOPS = {"inner": 30, "sphere": 25, "msphere": 40, "rect": 15, "box6": 90, "triangle": 45, "xf_enter": 12, "xf_exit": 12, "medium": 40}
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 # Algorithmic bytes of one closest-hit query: 64 (ray in) + 32 per stream entry fetched + the f64 row of every
@@ -74,6 +89,36 @@ def measured_traffic(workload, spp):
     if not t or t.get("spp_per_step") != spp:
         return None
     return t["bytes_per_launch"]
+
+
+def measured_valu(workload):
+    """What the committed SQ counter passes say about the closest-hit kernel (profiles/valu_issue.json): share of
+    issue cycles with a vector instruction, active-lane fraction, f64 lane-operations per second; None if absent."""
+    path = os.path.join(ROOT, "profiles", "valu_issue.json")
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path)).get(workload)
+
+
+def algorithmic_flops(work):
+    return sum(FLOPS[k] * work[k] for k in FLOPS)
+
+
+def self_launch(args):
+    """--gpus N > 1 outside torch.distributed.run: start the N ranks as a child job and relay it. Nothing in this
+    process has initialised the GPU yet (torch is imported, no device call made), and the child is a new process,
+    not a replacement of this one."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
 
 
 def algorithmic_bytes(rays, work):
@@ -128,17 +173,23 @@ def main():
                          "or replaced by the linear BVH built on the GPU (rt_bvh_build)")
     ap.add_argument("--boxes-per-side", type=int, default=0,
                     help="final scene only: side of the ground grid of boxes (src/main.rs:591 has 20); larger grids no longer fit LDS")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every GPU renders --spp-per-step samples per step; strong: a step is a fixed job of --spp samples of every pixel split over the GPUs")
+    ap.add_argument("--spp", type=int, default=10000, help="--scaling strong: samples of every pixel in the whole job (BASELINE configs[3]: 10000)")
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the CPU baseline run (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=8, help="the reference's own thread count (src/main.rs:189)")
     ap.add_argument("--cpu-more-threads", type=int, default=16,
                     help="a second CPU run with this many threads (the CPU share of a one-GPU job on the box; 0 = skip)")
     args = ap.parse_args()
 
+    under_launcher = "WORLD_SIZE" in os.environ
+    if not under_launcher and args.gpus > 1:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: they must agree" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no fallback)")
     # RT_BENCH_REHEARSAL=1: several ranks share the GPUs that exist and talk over gloo, to exercise the N > 1
@@ -147,7 +198,10 @@ def main():
     if rehearsal:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under a launcher the process group is made even for one rank, so that the all-reduce below goes through RCCL
+    # on a one-GPU box as well
+    use_dist = world > 1 or under_launcher
+    if use_dist:
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -167,21 +221,40 @@ def main():
     cam = L.host.camera(su)
     W, H = wl["width"], wl["height"]
     S = args.spp_per_step
+    # 232 bytes of path state per slot; never more than 60 % of what is free on this GPU
+    free_bytes, _ = torch.cuda.mem_get_info()
+    s_max = max(1, min(1024, (672 << 20) // (W * H), int(0.6 * free_bytes) // (232 * W * H)))
     if not S:
-        # 232 bytes of path state per slot; never more than 60 % of what is free on this GPU
-        free_bytes, _ = torch.cuda.mem_get_info()
-        S = max(1, min(1024, (672 << 20) // (W * H), int(0.6 * free_bytes) // (232 * W * H)))
+        S = s_max
     bg = list(su.background)
     accum = torch.zeros(H, W, 3, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    strong = args.scaling == "strong"
+    if strong:
+        # the job: args.spp samples of every pixel; this rank's share, cut into equal batches of at most s_max samples
+        lo, hi = shard_samples(0, args.spp, rank, world)
+        batches = equal_batches(lo, hi, args.spp_per_step or s_max)
+        S = max((b - a for a, b in batches), default=0)
+
+    launches = [0]
 
     def step(i, stats):
-        # global step i: rank r renders samples [ (i*world + r)*S, +S ) of every pixel
+        if strong:
+            # step i renders the whole job again, with other samples: [i * spp + lo, i * spp + hi)
+            tot = abi.RtRenderStats()
+            for a, b in batches:
+                ds.render_device(cam, lib.make_params(W, H, i * args.spp + a, i * args.spp + b, bg, samples_per_batch=b - a), accum.data_ptr(), stream, stats=stats)
+                tot.ms_extend += stats.ms_extend; tot.ms_shade += stats.ms_shade; tot.rays += stats.rays
+                launches[0] += 50
+            stats.ms_extend, stats.ms_shade, stats.rays = tot.ms_extend, tot.ms_shade, tot.rays
+            return
+        # weak: global step i: rank r renders samples [ (i*world + r)*S, +S ) of every pixel
         s0 = (i * world + rank) * S
         ds.render_device(cam, lib.make_params(W, H, s0, s0 + S, bg, samples_per_batch=S), accum.data_ptr(), stream, stats=stats)
+        launches[0] += 50
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -191,6 +264,7 @@ def main():
     barrier()
     ms_extend = ms_shade = 0.0
     rays = 0
+    launches[0] = 0
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i, st)
@@ -205,46 +279,64 @@ def main():
         allreduce_accum(accum)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    samples_total = world * W * H * S * args.steps
+    samples_total = (W * H * args.spp if strong else world * W * H * S) * args.steps
+    own_samples = (W * H * (hi - lo) if strong else W * H * S) * args.steps  # of this rank, what `rays` counts
     if rank == 0:
         # algorithmic bytes of the extend launches: instrumented pass over one step's samples, outside the timed region
         scratch = torch.zeros_like(accum)
         s0 = args.warmup * world * S
         wst, work = ds.render_work(cam, lib.make_params(W, H, s0, s0 + S, bg, samples_per_batch=S), scratch.data_ptr(), stream)
         bytes_per_ray = algorithmic_bytes(wst.rays, work) / max(1, wst.rays)
-        launches = args.steps * 50
+        flops_per_ray = algorithmic_flops(work) / max(1, wst.rays)
+        launches = max(1, launches[0])
         d = hs.desc
         table_bytes = int(32 * d.n_nodes + 40 * d.n_spheres + 80 * d.n_msphere + 56 * d.n_rects + 56 * d.n_boxes + 80 * d.n_triangles +
                           72 * d.n_xforms + 24 * d.n_media)
-        achieved = rays * bytes_per_ray / (ms_extend * 1e-3) / 1e9 if ms_extend > 0 else 0.0
+        in_lds = bool(table_bytes <= 144 * 1024)
+        secs_extend = ms_extend * 1e-3
+        gbs = rays * bytes_per_ray / secs_extend / 1e9 if ms_extend > 0 else 0.0
+        tflops = rays * flops_per_ray / secs_extend / 1e12 if ms_extend > 0 else 0.0
+        traffic = measured_traffic(args.workload, S) if args.bvh in ("reference", "lbvh") else None
+        byte_side = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": rays * bytes_per_ray / launches, "bytes_per_ray": bytes_per_ray,
+                     "measured_hbm_bytes_per_launch": traffic,
+                     "measured_hbm_frac": (traffic / (secs_extend / launches) / 1e9 / HBM_PEAK_GBS) if traffic and ms_extend > 0 else None}
+        flop_side = {"achieved": tflops, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_PEAK_TFLOPS,
+                     "algorithmic_flops_per_ray": flops_per_ray, "measured": measured_valu(args.workload)}
+        # What binds: with the scene tables staged in LDS the entry and primitive bytes never leave the CU (HBM carries
+        # only ray records and hit slots), and the kernel is bound by f64 vector issue at low lane utilisation; the byte
+        # formula is then reported beside it, not as the bound. A scene whose tables stay in global memory is HBM /
+        # L2-latency bound and the byte formula is the roofline.
+        head = flop_side if in_lds else byte_side
+        roofline = {"bound": "valu_f64" if in_lds else "hbm", "kernel": "k_extend", "served_from": "lds" if in_lds else "hbm",
+                    "achieved": head["achieved"], "peak": head["peak"], "unit": head["unit"], "frac": head["frac"],
+                    "traffic": traffic, "bytes": byte_side, "flops": flop_side,
+                    "entries_per_ray": work["entries"] / max(1, wst.rays),
+                    "visits_per_ray": {k: round(work[k] / max(1, wst.rays), 4) for k in ROW_BYTES},
+                    "ms_extend_per_step": ms_extend / args.steps, "ms_shade_per_step": ms_shade / args.steps,
+                    "avg_launch_ms": ms_extend / launches, "launches": launches,
+                    "tables_in_lds": in_lds, "table_bytes": table_bytes}
         out = {
             "metric": "path samples/s", "value": samples_total / elapsed, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, not a measurement)",
-            "config": {"workload": wl["name"], "width": W, "height": H, "spp_per_step_per_gpu": S, "max_depth": 50, "bvh": args.bvh, "scene_build_s": round(t_build, 3),
-                       "sharding": "sample ranges per rank, one RCCL all-reduce of the f32 accumulation buffer"},
-            "mrays_per_s": rays * world / elapsed / 1e6 if world == 1 else None,
-            "rays_per_sample": rays / (W * H * S * args.steps),
-            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, S) if args.bvh == "reference" else None,
-                         "algorithmic_bytes_per_launch": rays * bytes_per_ray / launches,
-                         "bytes_per_ray": bytes_per_ray, "entries_per_ray": work["entries"] / max(1, wst.rays),
-                         "visits_per_ray": {k: round(work[k] / max(1, wst.rays), 4) for k in ROW_BYTES},
-                         "ms_extend_per_step": ms_extend / args.steps, "ms_shade_per_step": ms_shade / args.steps,
-                         "avg_launch_ms": ms_extend / launches,
-                         "tables_in_lds": bool(table_bytes <= 144 * 1024), "table_bytes": table_bytes,
-                         "note": ("scene tables are staged in LDS: the kernel is f64-VALU / latency bound, HBM only carries the ray records"
-                                  if table_bytes <= 144 * 1024 else "scene tables are read from HBM / L2")},
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, not a measurement)",
+            "config": {"workload": wl["name"], "width": W, "height": H, "max_depth": 50, "bvh": args.bvh, "scene_build_s": round(t_build, 3),
+                       "sharding": "sample ranges per rank, one RCCL all-reduce of the f32 accumulation buffer",
+                       **({"spp_total": args.spp, "spp_this_rank": hi - lo, "batches_per_step": len(batches), "spp_per_batch": S} if strong
+                          else {"spp_per_step_per_gpu": S})},
+            "mrays_per_s": rays / max(1, own_samples) * samples_total / elapsed / 1e6,
+            "rays_per_sample": rays / max(1, own_samples),
+            "roofline": roofline,
         }
         if args.cpu_spp > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_spp, args.cpu_threads, args.cpu_more_threads)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

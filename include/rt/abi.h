@@ -117,8 +117,15 @@ typedef struct RtImage {         /* src/texture.rs:75-79; texels are RGB u8 rows
     uint32_t width, height; uint64_t offset;   /* byte offset into RtSceneDesc.texels */
 } RtImage;
 
+/* RtSceneDesc.flags. BOXES_MAY_NOT_BOUND: some BVHNode box does not bound what is under it (the reference's
+ * random_scene builds its tree over t in (0, 0.1) while its spheres move over (0, 1): src/main.rs:315, 267-279).
+ * The closest hit then depends on the box rule, and the kernels run the reference's own per-axis rule
+ * (src/aabb.rs:15-30) on such a scene instead of the tighter carried-interval rule they use everywhere else
+ * (the two agree whenever boxes bound their contents). */
+#define RT_DESC_BOXES_MAY_NOT_BOUND 1u
+
 typedef struct RtSceneDesc {
-    uint32_t abi_version; uint32_t _pad;
+    uint32_t abi_version; uint32_t flags;
     const RtNode* nodes; uint64_t n_nodes;
     const RtSphere* spheres; uint64_t n_spheres;
     const RtMovingSphere* msphere; uint64_t n_msphere;
@@ -246,7 +253,8 @@ typedef struct RtPathStep {
  * (pixel, sample). `profile` selects the variant of the closest-hit kernel: RT_PROFILE_OWN = the one rt_render
  * runs for this scene; otherwise a bit set (1: boxes alone inside wrappers handled in one step, 2: general walk of
  * medium boundaries, 4: lanes leave the box phase by vote) which must be one of 0, 1, 3, 4, 5, 7 and able to
- * handle the scene's media (RT_E_INVALID otherwise). `work`, when not NULL, receives the traversal work of the
+ * handle the scene's media (RT_E_INVALID otherwise); on a scene flagged RT_DESC_BOXES_MAY_NOT_BOUND bit 8 (the
+ * per-axis box rule) is implied and only 0 and 4 may be asked for. `work`, when not NULL, receives the traversal work of the
  * closest-hit launches (10 words as in rt_trace_work). Host buffers. */
 int rt_path_step(RtScene* scene, const RtRenderParams* params, int profile, const RtRay* rays, uint64_t n, RtPathStep* out,
                  uint64_t* work);

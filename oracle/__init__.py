@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 AABB_REFERENCE = 0  # src/aabb.rs:15-30 as written
-AABB_TIGHT = 1      # carried slab test on f32 boxes (what the HIP path runs)
+AABB_TIGHT = 1      # carried slab test on f32 boxes (what the HIP path runs where boxes bound their contents)
+AABB_PER_AXIS_F32 = 2  # the reference's per-axis rule on the f32 boxes (what the HIP path runs where they may not)
 
 STAT_NAMES = ("box_tests", "sphere", "msphere", "rect", "box6", "triangle", "medium", "rays")
 

@@ -48,7 +48,7 @@ constexpr double INF = std::numeric_limits<double>::infinity();  // src/rtweeken
 constexpr double PI = 3.14159265358979323846264338327950288;      // src/rtweekend.rs:4
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
-enum AabbMode : int { AABB_REFERENCE = 0, AABB_TIGHT = 1 };
+enum AabbMode : int { AABB_REFERENCE = 0, AABB_TIGHT = 1, AABB_PER_AXIS_F32 = 2 };
 
 enum PrimKind : int { K_SPHERE = 0, K_MSPHERE, K_RECT, K_BOX6, K_TRIANGLE, K_MEDIUM, K_NKINDS };
 
@@ -235,6 +235,19 @@ struct FBox {
             hi_t = std::fmin(t1, hi_t);
         }
         return !(hi_t <= lo_t);
+    }
+    // The reference's per-axis rule (src/aabb.rs:15-30: tmin / tmax not carried between axes, t = (plane - origin) *
+    // (1 / d)) on the f32 planes: what the HIP kernels run on scenes whose boxes may not bound their contents.
+    bool hit_per_axis(const Ray& r, double tmin, double tmax) const {
+        if (tmin != tmin || tmax != tmax) return true;
+        for (int a = 0; a < 3; ++a) {
+            const double inv_d = 1.0 / r.dire[a];
+            const bool neg = inv_d < 0.0;
+            const double t0 = ((double)(neg ? hi[a] : lo[a]) - r.orig[a]) * inv_d;
+            const double t1 = ((double)(neg ? lo[a] : hi[a]) - r.orig[a]) * inv_d;
+            if (std::fmin(t1, tmax) <= std::fmax(t0, tmin)) return false;
+        }
+        return true;
     }
 };
 
@@ -862,6 +875,8 @@ struct BVHNode : Hittable {  // :10-15
         ++tls.n_box;
         if (tls.aabb_mode == AABB_TIGHT) {
             if (!fbox.hit(r, t_min, t_max)) return false;
+        } else if (tls.aabb_mode == AABB_PER_AXIS_F32) {
+            if (!fbox.hit_per_axis(r, t_min, t_max)) return false;
         } else {
             if (!_box.hit(r, t_min, t_max)) return false;
         }

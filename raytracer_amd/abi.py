@@ -68,7 +68,7 @@ class RtImage(C.Structure):
 
 
 class RtSceneDesc(C.Structure):
-    _fields_ = [("abi_version", C.c_uint32), ("_pad", C.c_uint32),
+    _fields_ = [("abi_version", C.c_uint32), ("flags", C.c_uint32),
                 ("nodes", C.POINTER(RtNode)), ("n_nodes", C.c_uint64),
                 ("spheres", C.POINTER(RtSphere)), ("n_spheres", C.c_uint64),
                 ("msphere", C.POINTER(RtMovingSphere)), ("n_msphere", C.c_uint64),
@@ -133,6 +133,7 @@ class RtSceneSetup(C.Structure):
                 ("background", d3), ("samples_per_pixel", C.c_uint32), ("width", C.c_uint32)]
 
 
+RT_DESC_BOXES_MAY_NOT_BOUND = 1
 RT_SCENE_BVH_SHUTTER_TIMES = 1
 RT_SCENE_BVH_WIDEST_AXIS = 2
 RT_SCENE_BVH_LBVH = 4

@@ -201,7 +201,7 @@ constexpr uint32_t OUT_CHUNK = RT_OUT_CHUNK;  // output records a shading wave r
 #endif
 constexpr uint32_t OUT_MIN_CHUNKS = RT_OUT_MIN_CHUNKS;  // ... "many" = at least this many chunks of input per wave
 
-template <bool COUNT, bool BOXMEDIA, bool GENERAL, uint32_t VOTE_DEN, class SC, class IO>
+template <bool COUNT, bool BOXMEDIA, bool GENERAL, uint32_t VOTE_DEN, bool PER_AXIS, class SC, class IO>
 RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
     Work work;
     if (COUNT) { work.entries = 0; for (int k = 0; k < 9; ++k) work.prim[k] = 0; }
@@ -223,7 +223,7 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
         c_next = wave_id * share < n ? wave_id * share : n;
         c_end = c_next + share < n ? c_next + share : n;
     }
-    Walker<COUNT, BOXMEDIA, GENERAL> w;
+    Walker<COUNT, BOXMEDIA, GENERAL, PER_AXIS> w;
     w.done = true;
     typename IO::Ray ray;
     uint32_t index = 0u;
@@ -289,7 +289,6 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
 }
 
 // ---- stand-alone closest hit (rt_trace_closest / rt_trace_records) ---------------------
-template <bool RECORDS>
 struct TraceIO {
     const RtRay* rays;
     uint64_t n_rays, seed;
@@ -314,7 +313,7 @@ struct TraceIO {
     RT_D void store(const SC& S, uint32_t i, const Ray& r, const Cand& best) const {
         V3 o, d;
         r.rs.load(o, d);
-        if (RECORDS) {
+        if (recs) {
             RtHitRecord out;
             out.prim_id = RT_MISS; out.sub = 0u; out.mat = RT_NONE; out.front_face = 0u;
             out.t = 0.0; out.u = 0.0; out.v = 0.0;
@@ -342,21 +341,22 @@ struct TraceIO {
     }
 };
 
-// LDS = true: every table the kernel reads (all but images / texels) is staged in LDS first.
-template <bool RECORDS, bool COUNT, bool LDS>
+// LDS = true: every table the kernel reads (all but images / texels) is staged in LDS first. PER_AXIS: the
+// reference's own box rule (see Walker). Writes RtHitRecords when `recs` is not null, else RtHits.
+template <bool COUNT, bool LDS, bool PER_AXIS>
 __global__ void __launch_bounds__(TRACE_BLOCK, 2) k_trace(DevScene S0, LdsPlan plan, const RtRay* __restrict__ rays, uint64_t n, uint64_t seed,
                                                         RtHit* __restrict__ hits, RtHitRecord* __restrict__ recs,
                                                         uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
-    TraceIO<RECORDS> io;
+    TraceIO io;
     io.rays = rays; io.n_rays = n; io.seed = seed; io.hits = hits; io.recs = recs;
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
-        extend_pool<COUNT, false, true, 0u>(S, io, cursor, work_out);
+        extend_pool<COUNT, false, true, 0u, PER_AXIS>(S, io, cursor, work_out);
     } else if (plan_is_empty(plan)) {
-        extend_pool<COUNT, false, true, 0u>(S0, io, cursor, work_out);
+        extend_pool<COUNT, false, true, 0u, PER_AXIS>(S0, io, cursor, work_out);
     } else {
         const DevScene S = stage_scene_partial(S0, plan);
-        extend_pool<COUNT, false, true, 0u>(S, io, cursor, work_out);
+        extend_pool<COUNT, false, true, 0u, PER_AXIS>(S, io, cursor, work_out);
     }
 }
 
@@ -442,7 +442,8 @@ struct ExtendIO {
 // counts[0], counts[1]: lengths of the two record arrays; counts[2]: the ray cursor of this launch (zero on
 // entry, reset by the shade launch that follows).
 // PROFILE bits: 1 = the scene has boxes alone inside wrappers, 2 = it has media that need the general boundary walk
-// (set together with 1), 4 = lanes leave the box phase by vote (entry streams of 128 entries and more); see Walker.
+// (set together with 1), 4 = lanes leave the box phase by vote (entry streams of 128 entries and more), 8 = the
+// reference's per-axis box rule (scenes whose boxes may not bound their contents; built without bits 1 and 2); see Walker.
 // Without bit 2 the kernel runs 16 waves per CU, with it 12.
 constexpr int extend_block(bool lds, int profile) { return (profile & 2) ? (lds ? EXT_BLOCK : EXT_BLOCK_GLOBAL) : EXT_BLOCK_LEAN; }
 constexpr int extend_waves(bool lds, int profile) { return (profile & 2) ? (lds ? RT_EXTEND_WAVES : RT_EXTEND_WAVES_GLOBAL) : 4; }
@@ -457,12 +458,12 @@ __global__ void __launch_bounds__(extend_block(LDS, PROFILE), extend_waves(LDS, 
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[cur ^ 1u] = 0u;  // the array the following shade launch appends to
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
-        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? RT_VOTE_DEN : 0u>(S, io, counts + 2, work_out);
+        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? RT_VOTE_DEN : 0u, (PROFILE & 8) != 0>(S, io, counts + 2, work_out);
     } else if (plan_is_empty(plan)) {
-        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? RT_VOTE_DEN : 0u>(S0, io, counts + 2, work_out);
+        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? RT_VOTE_DEN : 0u, (PROFILE & 8) != 0>(S0, io, counts + 2, work_out);
     } else {
         const DevScene S = stage_scene_partial(S0, plan);
-        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? RT_VOTE_DEN : 0u>(S, io, counts + 2, work_out);
+        extend_pool<COUNT, (PROFILE & 1) != 0, (PROFILE & 2) != 0, (PROFILE & 4) ? RT_VOTE_DEN : 0u, (PROFILE & 8) != 0>(S, io, counts + 2, work_out);
     }
 }
 

@@ -176,6 +176,32 @@ RT_D bool box_hit(const uint4 na, const uint4 nb, const Seg& g, double tmin, dou
     return !(hi <= lo) || (tmin != tmin) || (tmax != tmax);
 }
 
+// The reference's own rule (src/aabb.rs:15-30): tmin / tmax are not carried from axis to axis, the box passes when
+// on every axis by itself the slab interval clipped to [tmin, tmax] is not empty. Looser than the carried test; the
+// two find the same closest hit when boxes bound their contents, and differ when they do not (a MovingSphere in a
+// tree built over a shorter time interval than its motion, src/main.rs:315). Used for scenes flagged
+// RT_DESC_BOXES_MAY_NOT_BOUND; the planes are the f32 outward-rounded ones of the stream.
+RT_D bool box_hit_per_axis(const uint4 na, const uint4 nb, const Seg& g, double tmin, double tmax) {
+    const float lox = __uint_as_float(na.x), loy = __uint_as_float(na.y), loz = __uint_as_float(na.z);
+    const float hix = __uint_as_float(na.w), hiy = __uint_as_float(nb.x), hiz = __uint_as_float(nb.y);
+    const bool sx = g.invd.x < 0.0, sy = g.invd.y < 0.0, sz = g.invd.z < 0.0;
+    // (plane - origin) * (1 / d), the reference's own form (:18-19): unlike the fused form of box_hit it stays +-inf,
+    // not NaN, for a ray that runs parallel to the slab outside it, and such a ray must miss a box that is relied on
+    // to clip
+    const double t0x = ((double)(sx ? hix : lox) - g.o.x) * g.invd.x;
+    const double t1x = ((double)(sx ? lox : hix) - g.o.x) * g.invd.x;
+    const double t0y = ((double)(sy ? hiy : loy) - g.o.y) * g.invd.y;
+    const double t1y = ((double)(sy ? loy : hiy) - g.o.y) * g.invd.y;
+    const double t0z = ((double)(sz ? hiz : loz) - g.o.z) * g.invd.z;
+    const double t1z = ((double)(sz ? loz : hiz) - g.o.z) * g.invd.z;
+    // t0 = t0 > tmin ? t0 : tmin; t1 = t1 < tmax ? t1 : tmax; fail when t1 <= t0 (:23-25); a NaN t0 / t1 gives way
+    // to tmin / tmax, as the comparisons of the reference do
+    const bool fx = fmin(t1x, tmax) <= fmax(t0x, tmin);
+    const bool fy = fmin(t1y, tmax) <= fmax(t0y, tmin);
+    const bool fz = fmin(t1z, tmax) <= fmax(t0z, tmin);
+    return !(fx || fy || fz) || (tmin != tmin) || (tmax != tmax);
+}
+
 // ---- primitives -----------------------------------------------------------------
 // Every primitive test below evaluates the reference's expressions in the reference's order.
 
@@ -313,7 +339,9 @@ RT_D bool diag_first_lane() { return (int)__lane_id() == __ffsll((unsigned long 
 // GENERAL: the scene has a ConstantMedium whose boundary is anything else than one sphere or one (wrapped) box, so the
 // re-entrant boundary walk (modes 1 and 2 and the parked world result) is needed. Without it the walker fits 128
 // registers and the kernel runs four waves per SIMD instead of three.
-template <bool COUNT, bool BOXMEDIA = false, bool GENERAL = true>
+// PER_AXIS: box entries are tested with the reference's per-axis rule (box_hit_per_axis) instead of the carried
+// interval; for scenes whose boxes may not bound their contents.
+template <bool COUNT, bool BOXMEDIA = false, bool GENERAL = true, bool PER_AXIS = false>
 struct Walker {
     Seg g;
     double tm, tmin0, tmin;
@@ -386,7 +414,7 @@ struct Walker {
                     if (COUNT) { work->entries++; work->prim[nb.z & 15u]++; }
 #endif
                     if ((nb.z & 15u) != RT_N_INNER) { leaf_found = true; break; }
-                    j = box_hit(na, nb, g, lo, hi) ? j + 1u : nb.w;
+                    j = (PER_AXIS ? box_hit_per_axis(na, nb, g, lo, hi) : box_hit(na, nb, g, lo, hi)) ? j + 1u : nb.w;
                     if (VOTE_DEN != 0u && (uint32_t)__popcll(__ballot(1)) * VOTE_DEN < n_in) { i = j; return false; }
                 }
                 i = j;

@@ -14,6 +14,7 @@ struct RtHostScene {
     RtSceneDesc desc{};
     void bind() {
         desc.abi_version = RT_ABI_VERSION;
+        desc.flags = flat.boxes_may_not_bound ? RT_DESC_BOXES_MAY_NOT_BOUND : 0u;
         desc.nodes = flat.nodes.data(); desc.n_nodes = flat.nodes.size();
         desc.spheres = flat.spheres.data(); desc.n_spheres = flat.spheres.size();
         desc.msphere = flat.msphere.data(); desc.n_msphere = flat.msphere.size();

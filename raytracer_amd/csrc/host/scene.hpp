@@ -118,6 +118,10 @@ struct Flat {
     std::unordered_map<const void*, uint32_t> seen;  // object -> table index, so shared objects are stored once
     std::vector<uint32_t> xf_stack;
     bool in_medium = false;
+    // the time interval every BVHNode around the object being flattened was built over (their intersection), and
+    // whether some object moves outside it: its boxes then do not bound it (RT_DESC_BOXES_MAY_NOT_BOUND)
+    double cover_t0 = -std::numeric_limits<double>::infinity(), cover_t1 = std::numeric_limits<double>::infinity();
+    bool boxes_may_not_bound = false;
 
     uint32_t push_node(uint32_t kind, uint32_t index, uint32_t link = 0) {
         if (index >= (1u << 28)) throw std::length_error("table index exceeds 28 bits");
@@ -316,6 +320,9 @@ struct MovingSphere : Hittable {  // src/hittable.rs:187-212, 248-259
         return true;
     }
     void flatten(Flat& f) const override {
+        // MovingSphere::bounding_box(t0, t1) bounds the sphere for times in [t0, t1] only (src/hittable.rs:248-259)
+        const bool moves = center0.x != center1.x || center0.y != center1.y || center0.z != center1.z;
+        if (moves && (std::fmin(time0, time1) < f.cover_t0 || std::fmax(time0, time1) > f.cover_t1)) f.boxes_may_not_bound = true;
         auto it = f.seen.find(this);
         uint32_t idx;
         if (it != f.seen.end()) idx = it->second;
@@ -533,11 +540,26 @@ struct ConstantMedium : Hittable {  // src/constant_medium.rs:10-31, 91-93
     }
 };
 
+// Narrows the time interval the flattener knows the enclosing trees were built over, for the duration of a subtree.
+struct CoverScope {
+    Flat& f;
+    double t0, t1;
+    CoverScope(Flat& f_, float time0, float time1) : f(f_), t0(f_.cover_t0), t1(f_.cover_t1) {
+        f.cover_t0 = std::fmax(f.cover_t0, (double)time0);
+        f.cover_t1 = std::fmin(f.cover_t1, (double)time1);
+    }
+    ~CoverScope() { f.cover_t0 = t0; f.cover_t1 = t1; }
+};
+
 struct BVHNode : Hittable {  // src/bvh.rs:10-15
     HitPtr left, right;
     AABB _box;
+    // the interval BVHNode::new was given (src/bvh.rs:94); f32 is enough to tell (0, 0.1) from (0, 1), rounded inward
+    float time0 = -std::numeric_limits<float>::infinity(), time1 = std::numeric_limits<float>::infinity();
+    void set_times(double t0, double t1) { time0 = f32_up(t0); time1 = f32_down(t1); }
     bool bounding_box(double, double, AABB& out) const override { out = _box; return true; }  // :113-116
     void flatten(Flat& f) const override {
+        CoverScope cover(f, time0, time1);
         const uint32_t at = f.push_node(RT_N_INNER, 0);
         RtNode& n = f.nodes[at];
         // A box that is flat on an axis is never hit by the reference's test (src/aabb.rs:25, t1 <= t0);
@@ -653,6 +675,7 @@ struct BvhBuild {
         if (!node->left->bounding_box(time0, time1, bl) || !node->right->bounding_box(time0, time1, br))
             throw std::runtime_error("object without a bounding box in BVHNode::new");  // :83-87
         node->_box = surrounding_box(bl, br);
+        node->set_times(time0, time1);
         return node;
     }
 };
@@ -673,6 +696,7 @@ struct DeviceBvh : BVHNode {  // left / right stay empty: the tree is held as pr
     double ms_device = 0.0;
 
     DeviceBvh(const std::vector<HitPtr>& list, double time0, double time1) : objects(list) {
+        set_times(time0, time1);
         std::vector<double> boxes(objects.size() * 6);
         for (size_t i = 0; i < objects.size(); ++i) {
             AABB b;
@@ -685,6 +709,7 @@ struct DeviceBvh : BVHNode {  // left / right stay empty: the tree is held as pr
         if (rc != RT_OK) throw AbiError(rc, rt_last_error());
     }
     void flatten(Flat& f) const override {
+        CoverScope cover(f, time0, time1);
         std::vector<std::pair<uint32_t, uint32_t>> open;  // (entry, token after its subtree)
         for (size_t k = 0; k < tokens.size(); ++k) {
             const RtNode& t = tokens[k];

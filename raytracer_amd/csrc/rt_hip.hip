@@ -58,6 +58,7 @@ struct RtScene {
     bool box_media = false;   // some box of six sides sits alone inside wrappers (on its own or as a medium's boundary)
     bool general_media = false;  // some medium's boundary is neither one sphere nor one box alone inside wrappers
     bool boxed_media = false;    // some medium's boundary is one box alone inside zero or more wrappers
+    bool per_axis = false;       // RT_DESC_BOXES_MAY_NOT_BOUND: the kernels run the reference's per-axis box rule
     int profile = 3;          // extend kernel profile (bits as in kernels.h): 1 box_media, 2 general boundary walk, 4 vote
     // Device staging areas of the entry points that take host buffers, kept between calls and grown on demand
     // (rt_trace_*, rt_render, rt_path_step): [0] input, [1] output, [2] small extras.
@@ -73,6 +74,7 @@ int validate(const RtSceneDesc* d) {
     auto bad = [](const char* what) { return rt::set_error(RT_E_INVALID, std::string("scene description: ") + what); };
     if (!d) return bad("null");
     if (d->abi_version != RT_ABI_VERSION) return bad("abi_version mismatch");
+    if (d->flags & ~RT_DESC_BOXES_MAY_NOT_BOUND) return bad("unknown flag");
     if (d->n_nodes >= 0xFFFFFFFFull) return bad("too many entries");
     const uint64_t counts[] = {d->n_nodes, d->n_spheres, d->n_msphere, d->n_rects, d->n_boxes, d->n_triangles, d->n_xforms,
                                d->n_media, d->n_materials, d->n_textures, d->n_perlins, d->n_images, d->n_texel_bytes};
@@ -237,6 +239,8 @@ void launch_extend(RtScene* s, int profile, bool count_work, const RenderConst& 
         case 3: RT_LAUNCH_EXTEND_P(3); break;
         case 4: RT_LAUNCH_EXTEND_P(4); break;
         case 5: RT_LAUNCH_EXTEND_P(5); break;
+        case 8: RT_LAUNCH_EXTEND_P(8); break;
+        case 12: RT_LAUNCH_EXTEND_P(12); break;
         default: RT_LAUNCH_EXTEND_P(7); break;
     }
 #undef RT_LAUNCH_EXTEND_P
@@ -395,6 +399,16 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         s->general_media = general_media;
         s->profile = (general_media ? 3 : (s->box_media ? 1 : 0)) | (d->n_nodes >= 128 ? 4 : 0);
         if (general_media) s->box_media = true;  // profile 3 compiles both in
+        s->per_axis = (d->flags & RT_DESC_BOXES_MAY_NOT_BOUND) != 0;
+        if (s->per_axis) {
+            // the per-axis variants are built without the one-step box code and the general boundary walk
+            if (general_media || s->boxed_media) {
+                rc = rt::set_error(RT_E_UNSUPPORTED, "RT_DESC_BOXES_MAY_NOT_BOUND on a scene with media bounded by anything but one sphere");
+                break;
+            }
+            s->box_media = false;
+            s->profile = 8 | (d->n_nodes >= 128 ? 4 : 0);
+        }
         // LDS plans: a kernel runs its LDS variant when every table it reads (all but images / texels) fits
         {
             const uint32_t kBudget = 144u * 1024u;  // of the 160 KiB of a CU; one workgroup per CU
@@ -482,22 +496,17 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
 #define RT_BIG_LDS(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, big)
 #define RT_BIG_LDS_P(PR) RT_BIG_LDS((rtd::k_extend<false, false, PR>)); RT_BIG_LDS((rtd::k_extend<false, true, PR>)); \
                          RT_BIG_LDS((rtd::k_extend<true, false, PR>)); RT_BIG_LDS((rtd::k_extend<true, true, PR>))
-            RT_BIG_LDS_P(0); RT_BIG_LDS_P(1); RT_BIG_LDS_P(3); RT_BIG_LDS_P(4); RT_BIG_LDS_P(5); RT_BIG_LDS_P(7);
+            RT_BIG_LDS_P(0); RT_BIG_LDS_P(1); RT_BIG_LDS_P(3); RT_BIG_LDS_P(4); RT_BIG_LDS_P(5); RT_BIG_LDS_P(7); RT_BIG_LDS_P(8); RT_BIG_LDS_P(12);
 #undef RT_BIG_LDS_P
-#undef RT_BIG_LDS
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlainBudget);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortBudget);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlainBudget);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortBudget);
+#define RT_BIG_LDS_T(W, L) RT_BIG_LDS((rtd::k_trace<W, L, false>)); RT_BIG_LDS((rtd::k_trace<W, L, true>))
+            RT_BIG_LDS_T(false, false); RT_BIG_LDS_T(false, true); RT_BIG_LDS_T(true, false); RT_BIG_LDS_T(true, true);
+#undef RT_BIG_LDS_T
+#undef RT_BIG_LDS
             (void)hipGetLastError();  // a refused attribute must not surface as the error of a later launch
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_trace<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
         }
         int per_cu = 0;
         hipError_t oe = hipErrorUnknown;
@@ -509,6 +518,8 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
             case 3: RT_OCC_P(3); break;
             case 4: RT_OCC_P(4); break;
             case 5: RT_OCC_P(5); break;
+            case 8: RT_OCC_P(8); break;
+            case 12: RT_OCC_P(12); break;
             default: RT_OCC_P(7); break;
         }
 #undef RT_OCC_P
@@ -564,12 +575,11 @@ int rt_trace_closest_device(RtScene* s, const RtRay* rays_dev, uint64_t n, uint6
     if (n >= (1ull << 32)) return rt::set_error(RT_E_INVALID, "too many rays in one call");
     if (int rc = ensure_workspace(s, 0)) return rc;
     HIP_TRY(hipMemsetAsync(s->ws.counts + 3, 0, sizeof(uint32_t), (hipStream_t)stream));
-    if (s->extend_lds)
-        hipLaunchKernelGGL((rtd::k_trace<false, false, true>), dim3(trace_grid(s, n)), dim3(rtd::TRACE_BLOCK), s->lds_bytes, (hipStream_t)stream, s->S, s->plan,
-                           rays_dev, n, seed, out_dev, (RtHitRecord*)nullptr, s->ws.counts + 3, (unsigned long long*)nullptr);
-    else
-        hipLaunchKernelGGL((rtd::k_trace<false, false, false>), dim3(trace_grid(s, n)), dim3(rtd::TRACE_BLOCK), s->lds_bytes, (hipStream_t)stream, s->S, s->plan,
-                           rays_dev, n, seed, out_dev, (RtHitRecord*)nullptr, s->ws.counts + 3, (unsigned long long*)nullptr);
+#define RT_LAUNCH_TRACE_DEV(L, A) hipLaunchKernelGGL((rtd::k_trace<false, L, A>), dim3(trace_grid(s, n)), dim3(rtd::TRACE_BLOCK), s->lds_bytes, (hipStream_t)stream, s->S, s->plan, \
+                                                     rays_dev, n, seed, out_dev, (RtHitRecord*)nullptr, s->ws.counts + 3, (unsigned long long*)nullptr)
+    if (s->extend_lds) { if (s->per_axis) RT_LAUNCH_TRACE_DEV(true, true); else RT_LAUNCH_TRACE_DEV(true, false); }
+    else { if (s->per_axis) RT_LAUNCH_TRACE_DEV(false, true); else RT_LAUNCH_TRACE_DEV(false, false); }
+#undef RT_LAUNCH_TRACE_DEV
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -606,16 +616,16 @@ int trace_host(RtScene* s, const RtRay* rays, uint64_t n, uint64_t seed, RtHit* 
     HIP_TRY(hipEventRecord(s->ev_trace[0], nullptr));
     RtHit* oh = recs ? nullptr : (RtHit*)d_out;
     RtHitRecord* orc = recs ? (RtHitRecord*)d_out : nullptr;
-#define RT_LAUNCH_TRACE(R, W, L) hipLaunchKernelGGL((rtd::k_trace<R, W, L>), grid, block, s->lds_bytes, nullptr, s->S, s->plan, d_rays, n, seed, oh, orc, cursor, d_work)
-    const int variant = (recs ? 4 : 0) | (work ? 2 : 0) | (s->extend_lds ? 1 : 0);
+#define RT_LAUNCH_TRACE(W, L, A) hipLaunchKernelGGL((rtd::k_trace<W, L, A>), grid, block, s->lds_bytes, nullptr, s->S, s->plan, d_rays, n, seed, oh, orc, cursor, d_work)
+    const int variant = (s->per_axis ? 4 : 0) | (work ? 2 : 0) | (s->extend_lds ? 1 : 0);
     switch (variant) {
         case 0: RT_LAUNCH_TRACE(false, false, false); break;
-        case 1: RT_LAUNCH_TRACE(false, false, true); break;
-        case 2: RT_LAUNCH_TRACE(false, true, false); break;
-        case 3: RT_LAUNCH_TRACE(false, true, true); break;
-        case 4: RT_LAUNCH_TRACE(true, false, false); break;
-        case 5: RT_LAUNCH_TRACE(true, false, true); break;
-        case 6: RT_LAUNCH_TRACE(true, true, false); break;
+        case 1: RT_LAUNCH_TRACE(false, true, false); break;
+        case 2: RT_LAUNCH_TRACE(true, false, false); break;
+        case 3: RT_LAUNCH_TRACE(true, true, false); break;
+        case 4: RT_LAUNCH_TRACE(false, false, true); break;
+        case 5: RT_LAUNCH_TRACE(false, true, true); break;
+        case 6: RT_LAUNCH_TRACE(true, false, true); break;
         default: RT_LAUNCH_TRACE(true, true, true); break;
     }
 #undef RT_LAUNCH_TRACE
@@ -659,9 +669,13 @@ int rt_scene_profile(const RtScene* s) {
 int rt_path_step(RtScene* s, const RtRenderParams* p, int profile, const RtRay* rays, uint64_t n, RtPathStep* out, uint64_t* work) {
     if (!s || !p || (n && (!rays || !out))) return rt::set_error(RT_E_INVALID, "null argument");
     if (work) std::memset(work, 0, kWorkWords * sizeof(uint64_t));
-    if (profile == RT_PROFILE_OWN) profile = s->profile;
+    if (profile == RT_PROFILE_OWN) profile = s->profile & ~8;
     if (profile != 0 && profile != 1 && profile != 3 && profile != 4 && profile != 5 && profile != 7)
         return rt::set_error(RT_E_INVALID, "profile must be one of 0, 1, 3, 4, 5, 7");
+    if (s->per_axis) {
+        if (profile & 3) return rt::set_error(RT_E_INVALID, "a scene whose boxes may not bound their contents runs profile 0 or 4 only");
+        profile |= 8;
+    }
     if (s->general_media && !(profile & 2)) return rt::set_error(RT_E_INVALID, "the scene's media need the general boundary walk (profile bit 2)");
     if (s->boxed_media && !(profile & 3)) return rt::set_error(RT_E_INVALID, "the scene's box-bounded media need profile bit 1 or 2");
     if (p->width < 2 || p->height < 2 || p->sample_end < p->sample_begin || p->max_depth > 0xFFFFu)

@@ -20,9 +20,21 @@ def shard_samples(sample_begin, sample_end, rank, world_size):
     return lo, hi
 
 
+def equal_batches(lo, hi, max_batch):
+    """Cuts samples [lo, hi) into the fewest batches of at most max_batch samples, sizes differing by at most 1: a
+    wavefront batch runs well below peak when it is small, so no short batch is left over at the end."""
+    total = hi - lo
+    if total <= 0:
+        return []
+    if max_batch < 1:
+        raise ValueError("bad batch size")
+    n = -(-total // max_batch)
+    return [shard_samples(lo, hi, k, n) for k in range(n)]
+
+
 def allreduce_accum(accum, group=None):
     """In-place sum of the per-rank accumulation buffers (float32 [H, W, 3]) over all ranks."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():  # also with one rank: the collective then runs through RCCL all the same
         dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
     return accum
 

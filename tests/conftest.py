@@ -60,3 +60,18 @@ def ulp_diff(a, b):
     ia = np.ascontiguousarray(a).view(np.int64)
     ib = np.ascontiguousarray(b).view(np.int64)
     return np.abs(ia - ib)
+
+
+def oracle_mode(host_scene):
+    """The oracle's box rule that matches what the HIP kernels run on this flattened scene: the carried-interval
+    rule, or the reference's per-axis rule where the scene's boxes may not bound their contents."""
+    import oracle
+    from raytracer_amd import abi
+    return oracle.AABB_PER_AXIS_F32 if host_scene.desc.flags & abi.RT_DESC_BOXES_MAY_NOT_BOUND else oracle.AABB_TIGHT
+
+
+def golden_mode(sid):
+    """The same for the committed golden vectors: scenes 1 is the reference's random_scene, whose tree is built over
+    t in (0, 0.1) while its spheres move over (0, 1) (src/main.rs:315)."""
+    import oracle
+    return oracle.AABB_PER_AXIS_F32 if sid in (1, 2) else oracle.AABB_TIGHT

@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import ROOT
-from raytracer_amd.distributed import render_sharded, shard_samples
+from raytracer_amd.distributed import equal_batches, render_sharded, shard_samples
 
 
 def test_shard_samples_partition():
@@ -26,6 +26,18 @@ def test_shard_samples_partition():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_samples(0, 8, 2, 2)
+
+
+def test_equal_batches_leave_no_runt():
+    # BASELINE configs[3] on 8 GPUs: 10 000 spp / 8 = 1250 per GPU; with at most 1024 per batch that is 2 x 625, not 1024 + 226
+    assert equal_batches(0, 1250, 1024) == [(0, 625), (625, 1250)]
+    assert equal_batches(10, 10, 5) == []
+    for total in (1, 7, 1024, 1025, 10000):
+        for mx in (1, 3, 1024):
+            parts = equal_batches(3, 3 + total, mx)
+            sizes = [b - a for a, b in parts]
+            assert parts[0][0] == 3 and parts[-1][1] == 3 + total and max(sizes) <= mx and max(sizes) - min(sizes) <= 1
+            assert len(parts) == -(-total // mx)
 
 
 def _worker(rank, world, port, out_path):

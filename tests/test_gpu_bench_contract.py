@@ -27,8 +27,11 @@ def test_bench_line_has_the_contract_fields(gpu):
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # the final scene's tables live in LDS: the closest-hit kernel is bound by f64 vector issue, not by HBM, and the
+    # line says so (there is no MFMA work in a path tracer); the byte formula is reported beside it
+    assert r["bound"] == "valu_f64" and r["served_from"] == "lds" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert r["bytes"]["unit"] == "GB/s" and r["bytes"]["peak"] == 8000.0 and r["bytes"]["achieved"] > 0
     assert r["traffic"] is None  # the committed counter passes are for the default batch size only
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):

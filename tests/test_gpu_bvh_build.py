@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import SEED, load_golden, scene_kwargs
+from conftest import SEED, load_golden, scene_kwargs, oracle_mode
 from raytracer_amd import abi, lib
 from test_bvh_tokens import box_sets
 from test_gpu_trace import compare_hits
@@ -74,7 +74,7 @@ def test_scene_with_device_built_trees(gpu, orc, sid):
     hs = lib.HostScene.build(sid, seed=SEED, flags=flags, **kw)
     ds = lib.DeviceScene(hs)
     osc = orc.api.scene_build(sid, seed=SEED, flags=flags, **kw)
-    oh, _, ost = orc.trace(osc, g["rays"], seed=SEED, mode=oracle.AABB_TIGHT)
+    oh, _, ost = orc.trace(osc, g["rays"], seed=SEED, mode=oracle_mode(hs))
     gh, work = ds.trace_work(g["rays"], seed=SEED)
     compare_hits(oh, gh, "scene %d, trees built on the device" % sid)
     # the same tree on both sides: exactly the same traversal work
@@ -94,7 +94,7 @@ def test_mesh_of_a_million_triangles(gpu, orc):
     cam = orc.api.camera(su)
     p = orc.make_params(128, 128, 0, 2, list(su.background), seed=SEED)
     rays = orc.harvest(osc, cam, p, n_paths=20000, max_rays=1 << 15, max_bounce=3)
-    oh, _, ost = orc.trace(osc, rays, seed=SEED, mode=oracle.AABB_TIGHT)
+    oh, _, ost = orc.trace(osc, rays, seed=SEED, mode=oracle_mode(hs))
     gh, work = ds.trace_work(rays, seed=SEED)
     compare_hits(oh, gh, "1M-triangle mesh, tree built on the device")
     assert work["inner"] == ost["box_tests"] and work["triangle"] == ost["triangle"]

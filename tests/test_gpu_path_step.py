@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import GOLDEN, SCENE_OPTS, SEED, load_golden, scene_kwargs, ulp_diff
+from conftest import GOLDEN, SCENE_OPTS, SEED, load_golden, scene_kwargs, ulp_diff, oracle_mode
 from raytracer_amd import abi, lib
 
 pytestmark = pytest.mark.gpu
@@ -31,6 +31,8 @@ T_SOLID, T_CHECKER, T_NOISE, T_IMAGE = range(4)
 def legal_profiles(hs):
     """Profiles able to walk this scene: a medium bounded by a box inside wrappers needs bit 1 or 2, a medium
     bounded by anything but one sphere or one such box needs bit 2 (mirrors the rule stated in include/rt/abi.h)."""
+    if hs.desc.flags & abi.RT_DESC_BOXES_MAY_NOT_BOUND:
+        return [0, 4]  # the per-axis box rule is built for these two only (and implied)
     nodes = hs.table("nodes")
     kinds = nodes["meta"] & 15
     need_general = need_box = False
@@ -114,12 +116,12 @@ def test_golden_rays_through_the_render_kernels(gpu, orc, sid):
     hs = lib.HostScene.build(sid, seed=SEED, **scene_kwargs(sid))
     ds = lib.DeviceScene(hs)
     osc = orc.api.scene_build(sid, seed=SEED, **scene_kwargs(sid))
-    _, _, ost = orc.trace(osc, g["rays"], seed=SEED, mode=oracle.AABB_TIGHT)
+    _, _, ost = orc.trace(osc, g["rays"], seed=SEED, mode=oracle_mode(hs))
     su = gpu.host.scene_setup(sid)
     p = lib.make_params(meta["width"], meta["height"], 0, 4, list(su.background), seed=SEED)
     mk, tk = material_kinds(hs, g["hits"])
     legal = legal_profiles(hs)
-    assert ds.profile() in legal
+    assert (ds.profile() & ~8) in legal  # bit 8, the per-axis box rule, is implied by the scene, not chosen
     for pr in PROFILES:
         if pr not in legal:
             with pytest.raises(lib.RtError):
@@ -154,8 +156,8 @@ def test_seeded_rays_through_the_render_kernels(gpu, orc, sid, extra):
     p = orc.make_params(W, int(W / su.aspect_ratio), 0, 4, list(su.background), seed=seed)
     rays = orc.harvest(osc, cam, p, n_paths=40000, max_rays=1 << 16, max_bounce=3)
     assert len(rays) > 30000
-    oh, _, ost = orc.trace(osc, rays, seed=seed, mode=oracle.AABB_TIGHT)
-    want = orc.path_step(osc, p, rays, mode=oracle.AABB_TIGHT)
+    oh, _, ost = orc.trace(osc, rays, seed=seed, mode=oracle_mode(hs))
+    want = orc.path_step(osc, p, rays, mode=oracle_mode(hs))
     mk, tk = material_kinds(hs, oh)
     seen = None
     for pr in legal_profiles(hs):
@@ -188,8 +190,8 @@ def test_random_scenes_through_the_render_kernels(gpu, orc, case):
     rays["sample"] = rng.integers(0, 4, n)
     rays["bounce"] = rng.integers(0, 4, n)
     p = lib.make_params(W, H, 0, 4, [0.3, 0.5, 0.7], seed=77)
-    oh, _, ost = orc.trace(oroot, rays, seed=77, mode=oracle.AABB_TIGHT)
-    want = orc.path_step(oroot, p, rays, mode=oracle.AABB_TIGHT)
+    oh, _, ost = orc.trace(oroot, rays, seed=77, mode=oracle_mode(hs))
+    want = orc.path_step(oroot, p, rays, mode=oracle_mode(hs))
     mk, tk = material_kinds(hs, oh)
     assert (want["prim_id"] != abi.RT_MISS).sum() > 100
     for pr in legal_profiles(hs):

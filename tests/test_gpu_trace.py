@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import CONFIG_SCENES, SCENE_OPTS, SEED, load_golden, scene_kwargs, ulp_diff
+from conftest import CONFIG_SCENES, SCENE_OPTS, SEED, load_golden, scene_kwargs, ulp_diff, oracle_mode
 from raytracer_amd import abi, lib
 
 pytestmark = pytest.mark.gpu
@@ -67,7 +67,7 @@ def test_seeded_ray_set_and_work_vs_oracle(gpu, orc, sid):
     p = orc.make_params(W, int(W / su.aspect_ratio), 0, 4, list(su.background), seed=seed)
     rays = orc.harvest(osc, cam, p, n_paths=40000, max_rays=1 << 16, max_bounce=3)
     assert len(rays) > 30000
-    oh, _, ost = orc.trace(osc, rays, seed=seed, mode=oracle.AABB_TIGHT)
+    oh, _, ost = orc.trace(osc, rays, seed=seed, mode=oracle_mode(hs))
     gh, work = ds.trace_work(rays, seed=seed)
     compare_hits(oh, gh, "scene %d" % sid)
     gh2, _ = ds.trace(rays, seed=seed)
@@ -90,7 +90,7 @@ def test_widest_axis_tree_parity_and_work(gpu, orc, sid):
     hs = lib.HostScene.build(sid, seed=SEED, flags=abi.RT_SCENE_BVH_WIDEST_AXIS, **kw)
     ds = lib.DeviceScene(hs)
     osc = orc.api.scene_build(sid, seed=SEED, flags=abi.RT_SCENE_BVH_WIDEST_AXIS, **kw)
-    oh, _, ost = orc.trace(osc, g["rays"], seed=SEED, mode=oracle.AABB_TIGHT)
+    oh, _, ost = orc.trace(osc, g["rays"], seed=SEED, mode=oracle_mode(hs))
     gh, work = ds.trace_work(g["rays"], seed=SEED)
     compare_hits(oh, gh, "scene %d, widest-axis tree" % sid)
     assert work["inner"] == ost["box_tests"] and work["triangle"] == ost["triangle"] and work["box6"] == ost["box6"]
@@ -112,7 +112,7 @@ def test_forked_host_bvh_build_is_the_oracles_tree(gpu, orc):
     cam = orc.api.camera(su)
     p = orc.make_params(128, 128, 0, 2, list(su.background), seed=SEED)
     rays = orc.harvest(osc, cam, p, n_paths=20000, max_rays=1 << 15, max_bounce=3)
-    oh, _, ost = orc.trace(osc, rays, seed=SEED, mode=oracle.AABB_TIGHT)
+    oh, _, ost = orc.trace(osc, rays, seed=SEED, mode=oracle_mode(hs))
     gh, work = ds.trace_work(rays, seed=SEED)
     compare_hits(oh, gh, "200k-triangle mesh")
     assert work["inner"] == ost["box_tests"] and work["triangle"] == ost["triangle"] and work["box6"] == ost["box6"]
@@ -209,7 +209,7 @@ def test_random_scenes_all_primitive_kinds(gpu, orc, case):
     hs = lib.HostScene(gpu, hroot)
     ds = lib.DeviceScene(hs)
     rays = random_rays(rng, 20000)
-    oh, orec, _ = orc.trace(oroot, rays, seed=77, mode=oracle.AABB_TIGHT, records=True)
+    oh, orec, _ = orc.trace(oroot, rays, seed=77, mode=oracle_mode(hs), records=True)
     gh, _ = ds.trace(rays, seed=77)
     compare_hits(oh, gh, "random scene %d" % case)
     grec = ds.trace_records(rays, seed=77)
@@ -221,6 +221,60 @@ def test_random_scenes_all_primitive_kinds(gpu, orc, case):
     ds.close()
     hs.close()
     orc.api.scene_free(oroot)
+
+
+def test_boxes_that_do_not_bound_their_spheres(gpu, orc):
+    # A tree built over t in (0, 0.2) around spheres that move over (0, 1), as the reference's random_scene does
+    # (src/main.rs:315): the closest hit then depends on the box rule. The flattener flags such a scene and the
+    # kernels run the reference's per-axis rule (src/aabb.rs:15-30) on it; the carried-interval rule would clip.
+    rng = np.random.default_rng(99)
+    roots = []
+    n_obj = 120
+    cs = rng.uniform(-5, 5, (n_obj, 3))
+    mv = rng.uniform(-1.5, 1.5, (n_obj, 3))
+    for api in (gpu.host, orc.api):
+        b = api.builder(seed=11)
+        m = b.lambertian([0.5, 0.5, 0.5])
+        objs = []
+        for k in range(n_obj):
+            if k % 3 == 0:
+                objs.append(b.sphere(cs[k], 0.4, m))
+            elif k % 3 == 1:
+                objs.append(b.moving_sphere(cs[k], cs[k] + mv[k], 0.0, 1.0, 0.35, m))
+            else:
+                objs.append(b.triangle(cs[k] + [0.8, 0, 0.1], cs[k] + [0, 0.8, -0.2], cs[k], m))
+        roots.append(b.finish(b.bvh(b.list(objs), 0.0, 0.2)))
+    hs = lib.HostScene(gpu, roots[0])
+    assert hs.desc.flags & abi.RT_DESC_BOXES_MAY_NOT_BOUND
+    ds = lib.DeviceScene(hs)
+    assert ds.profile() == 12  # per-axis box rule (8), and 239 entries: vote exit from the box phase (4)
+    rays = random_rays(rng, 30000)
+    oh, _, ost = orc.trace(roots[1], rays, seed=5, mode=oracle.AABB_PER_AXIS_F32)
+    gh, work = ds.trace_work(rays, seed=5)
+    d = compare_hits(oh, gh, "boxes that do not bound")
+    assert d.max(initial=0) == 0 and work["inner"] == ost["box_tests"] and work["msphere"] == ost["msphere"]
+    # the per-axis rule on the f32 boxes against the reference's on its f64 boxes: the same hits but for rays that pass
+    # within one f32 rounding of a box face
+    ref, _, _ = orc.trace(roots[1], rays, seed=5, mode=oracle.AABB_REFERENCE)
+    assert (ref["prim_id"] != oh["prim_id"]).sum() <= 2
+    tight, _, _ = orc.trace(roots[1], rays, seed=5, mode=oracle.AABB_TIGHT)
+    assert (tight["prim_id"] != oh["prim_id"]).sum() > 20  # the test tells the two rules apart
+    # the render kernels' own bounce on the same scene
+    rays["tmin"], rays["tmax"] = 1e-4, np.inf
+    rays["pixel"] = rng.permutation(256 * 128)[:len(rays)]
+    rays["sample"] = 0
+    rays["bounce"] = rng.integers(0, 4, len(rays))
+    p = lib.make_params(256, 128, 0, 1, [0.3, 0.5, 0.7], seed=5)
+    want = orc.path_step(roots[1], p, rays, mode=oracle.AABB_PER_AXIS_F32)
+    for pr in (0, 4):
+        got = ds.path_step(p, rays, profile=pr)
+        assert np.array_equal(want["prim_id"], got["prim_id"]) and np.array_equal(want["t"].view(np.uint64), got["t"].view(np.uint64))
+        assert np.array_equal(want["scattered"], got["scattered"]) and np.array_equal(want["o"], got["o"])
+    with pytest.raises(lib.RtError):
+        ds.path_step(p, rays, profile=1)
+    ds.close()
+    hs.close()
+    orc.api.scene_free(roots[1])
 
 
 def test_edge_cases(gpu, orc):
@@ -250,7 +304,7 @@ def test_edge_cases(gpu, orc):
     rays["d"][3 * n // 4:] = [0, 0, -1]
     rays[-1]["tmax"] = 0.5  # empty range
     rays[-2]["tmin"], rays[-2]["tmax"] = 3.0, 1.0  # inverted range
-    oh, _, _ = orc.trace(roots[1], rays, mode=oracle.AABB_TIGHT)
+    oh, _, _ = orc.trace(roots[1], rays, mode=oracle_mode(hs))
     gh, _ = ds.trace(rays)
     d = compare_hits(oh, gh, "edge cases")
     assert d.max(initial=0) == 0

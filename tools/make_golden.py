@@ -42,18 +42,25 @@ def main():
         W = 200
         H = int(W / su.aspect_ratio)
         p = o.make_params(W, H, 0, 4, list(su.background), seed=SEED)
-        rays = o.harvest(sc, cam, p, n_paths=3000, max_rays=4096, max_bounce=3)
-        hits, recs, stats = o.trace(sc, rays, seed=SEED, mode=oracle.AABB_TIGHT, records=True)
+        # the box rule the HIP kernels run on this scene: the reference's per-axis rule (on the f32 boxes) where boxes
+        # may not bound their contents (random_scene: tree over t in (0, 0.1), spheres moving over (0, 1)), else the
+        # carried-interval rule
+        mode = oracle.AABB_PER_AXIS_F32 if sid in (1, 2) else oracle.AABB_TIGHT
+        rays = o.harvest(sc, cam, p, n_paths=3000, max_rays=4096, max_bounce=3, mode=mode)
+        hits, recs, stats = o.trace(sc, rays, seed=SEED, mode=mode, records=True)
         hits_ref, _, stats_ref = o.trace(sc, rays, seed=SEED, mode=oracle.AABB_REFERENCE)
-        steps = o.path_step(sc, p, rays, mode=oracle.AABB_TIGHT)  # emitted / attenuation / scattered ray of each ray
+        hits_tight, _, _ = o.trace(sc, rays, seed=SEED, mode=oracle.AABB_TIGHT)
+        steps = o.path_step(sc, p, rays, mode=mode)  # emitted / attenuation / scattered ray of each ray
         np.savez_compressed(os.path.join(OUT, "trace_scene%02d.npz" % sid), rays=rays, hits=hits, records=recs,
                             hits_reference_aabb=hits_ref, steps=steps)
         meta["scenes"][str(sid)] = {
             "options": {k: v for k, v in opt.items()}, "width": W, "height": H, "n_rays": int(len(rays)),
             "n_scattered": int(steps["scattered"].sum()), "n_emitting": int((steps["emitted"] != 0).any(axis=1).sum()),
             "n_hits": int((hits["prim_id"] != 0xFFFFFFFF).sum()),
-            "box_tests_tight": int(stats["box_tests"]), "box_tests_reference": int(stats_ref["box_tests"]),
-            "ids_differ_tight_vs_reference": int((hits["prim_id"] != hits_ref["prim_id"]).sum()),
+            "box_rule": "per_axis_f32" if mode == oracle.AABB_PER_AXIS_F32 else "tight",
+            "box_tests": int(stats["box_tests"]), "box_tests_reference": int(stats_ref["box_tests"]),
+            "ids_differ_from_reference_rule": int((hits["prim_id"] != hits_ref["prim_id"]).sum()),
+            "ids_differ_tight_vs_reference_rule": int((hits_tight["prim_id"] != hits_ref["prim_id"]).sum()),
         }
         print(sid, meta["scenes"][str(sid)])
         o.api.scene_free(sc)
