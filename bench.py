@@ -79,9 +79,14 @@ def scene_kwargs(wl, bvh="reference"):
     return kw
 
 
+def profile_key(workload, bvh):
+    return workload if bvh == "reference" else "%s_%s" % (workload, bvh)
+
+
 def measured_traffic(workload, spp):
     """HBM bytes per extend launch from the committed rocprofv3 counter passes (profiles/hbm_traffic.json), or
-    None when there is no measurement for this workload and batch size: counters cannot be read from inside a run."""
+    None when there is no measurement for this workload, tree policy and batch size: counters cannot be read from
+    inside a run."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if not os.path.exists(path):
         return None
@@ -301,13 +306,13 @@ def main():
         secs_extend = ms_extend * 1e-3
         gbs = rays * bytes_per_ray / secs_extend / 1e9 if ms_extend > 0 else 0.0
         tflops = rays * flops_per_ray / secs_extend / 1e12 if ms_extend > 0 else 0.0
-        traffic = measured_traffic(args.workload, S) if args.bvh in ("reference", "lbvh") else None
+        traffic = measured_traffic(profile_key(args.workload, args.bvh), S)
         byte_side = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": rays * bytes_per_ray / launches, "bytes_per_ray": bytes_per_ray,
                      "measured_hbm_bytes_per_launch": traffic,
                      "measured_hbm_frac": (traffic / (secs_extend / launches) / 1e9 / HBM_PEAK_GBS) if traffic and ms_extend > 0 else None}
         flop_side = {"achieved": tflops, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_PEAK_TFLOPS,
-                     "algorithmic_flops_per_ray": flops_per_ray, "measured": measured_valu(args.workload)}
+                     "algorithmic_flops_per_ray": flops_per_ray, "measured": measured_valu(profile_key(args.workload, args.bvh))}
         # What binds: with the scene tables staged in LDS the entry and primitive bytes never leave the CU (HBM carries
         # only ray records and hit slots), and the kernel is bound by f64 vector issue at low lane utilisation; the byte
         # formula is then reported beside it, not as the bound. A scene whose tables stay in global memory is HBM /

@@ -1,0 +1,65 @@
+"""Turns the counter summaries of one tools/collect_profiles.sh run into the two small JSON files bench.py reads for
+its roofline object: profiles/hbm_traffic.json (HBM bytes per closest-hit launch) and profiles/valu_issue.json (vector
+issue and lane utilisation of the same kernel).
+
+    python tools/pmc_to_json.py KEY TAG KERNEL SPP SECONDS_PER_LAUNCH
+KEY: workload name as bench.py knows it, with the tree policy appended when not the reference's ("mesh_lbvh");
+TAG: the tag the summaries were written under (profiles/TAG_pmc_fetch.txt ...); KERNEL: e.g. "rtd::k_extend<false, true, 4>";
+SPP: samples per step of the profiled run; SECONDS_PER_LAUNCH: the kernel's average duration from the kernel trace."""
+import json
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def counters(path, kernel):
+    out, on = {}, False
+    for line in open(path):
+        if line.startswith(kernel + "  ("):
+            on = True
+            out["_dispatches"] = int(line.split("(")[-1].split()[0])
+            continue
+        if on:
+            if not line.strip():
+                break
+            parts = line.split()
+            if len(parts) == 2 and parts[0].isupper():
+                out[parts[0]] = float(parts[1])
+    return out
+
+
+def main(key, tag, kernel, spp, secs):
+    prof = os.path.join(ROOT, "profiles")
+    f = counters(os.path.join(prof, tag + "_pmc_fetch.txt"), kernel)
+    w = counters(os.path.join(prof, tag + "_pmc_write.txt"), kernel)
+    s = counters(os.path.join(prof, tag + "_pmc_issue.txt"), kernel)
+    n = f["_dispatches"]
+    raw = (f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024.0 / n
+    doubled = (2.0 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024.0 / n
+    path = os.path.join(prof, "hbm_traffic.json")
+    t = json.load(open(path)) if os.path.exists(path) else {}
+    t[key] = {"kernel": kernel, "launches": n, "fetch_size_kib": f["FETCH_SIZE"], "write_size_kib": w["WRITE_SIZE"],
+              "bytes_per_launch": doubled, "bytes_per_launch_uncorrected": raw,
+              "correction": "FETCH_SIZE doubled (gfx950 tallies 128-byte read requests at 64 bytes; exact for wide coalesced reads, "
+                            "an upper bound for scattered 32-byte entry reads); WRITE_SIZE as reported",
+              "source": "profiles/%s_pmc_fetch.txt and profiles/%s_pmc_write.txt (rocprofv3 --pmc, separate passes)" % (tag, tag),
+              "spp_per_step": int(spp)}
+    json.dump(t, open(path, "w"), indent=1)
+    lanes = s["SQ_THREAD_CYCLES_VALU"] / (s["SQ_ACTIVE_INST_VALU"] * 64.0)
+    lane_ops = s["SQ_INSTS_VALU"] * 64.0 * lanes / (s["_dispatches"] * float(secs))
+    path = os.path.join(prof, "valu_issue.json")
+    v = json.load(open(path)) if os.path.exists(path) else {}
+    v[key] = {"kernel": kernel, "active_lane_fraction": lanes,
+              "valu_active_per_wave_cycle": s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"],
+              "wave_cycles_waiting_on_memory_or_barrier": s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"],
+              "lane_ops_per_s": lane_ops, "lane_op_peak_per_s": 39.3e12, "lane_op_frac": lane_ops / 39.3e12,
+              "note": "lane_ops = SQ_INSTS_VALU x 64 x active-lane fraction / kernel time; peak = 256 CUs x 64 f64 lanes x 2.4 GHz (all vector instructions priced as f64)",
+              "source": "profiles/%s_pmc_issue.txt" % tag}
+    json.dump(v, open(path, "w"), indent=1)
+    print(json.dumps(t[key], indent=1))
+    print(json.dumps(v[key], indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:6])
