@@ -267,6 +267,26 @@ int rt_resolve_u8(const float* accum_rgb, uint32_t width, uint32_t height, uint6
 int rt_resolve_u8_device(const float* accum_rgb_dev, uint32_t width, uint32_t height, uint64_t spp, uint8_t* rgb_out_dev,
                          void* stream);
 
+/* ---- several GPUs in one process -------------------------------------------- */
+
+/* Stands in for the worker threads of the reference's driver (src/main.rs:189-230: 8 threads, each owning a band of
+ * image columns, merged by the caller): the scene is replicated in the HBM of every listed device, device i of G
+ * renders samples rt_shard_samples(sample_begin, sample_end, i, G) of EVERY pixel on its own stream from its own
+ * host thread, and one RCCL all-reduce (sum, float32, over xGMI) of the G accumulation buffers ends the render.
+ * The picture does not depend on G except for the order of the f32 additions. */
+typedef struct RtShardedScene RtShardedScene;
+/* devices: n_devices HIP device ordinals, distinct; NULL = the first n_devices devices (n_devices <= 0: all).
+ * RCCL is loaded at run time (librccl.so); with one device it is not needed. */
+int rt_sharded_create(const RtSceneDesc* desc, const int* devices, int n_devices, RtShardedScene** out);
+void rt_sharded_destroy(RtShardedScene* scene);
+int rt_sharded_device_count(const RtShardedScene* scene);
+/* As rt_render (host buffer, read-modify-write) over all devices of the scene. stats: paths and rays summed over
+ * the devices, times = the slowest device's. */
+int rt_sharded_render(RtShardedScene* scene, const RtCamera* cam, const RtRenderParams* params, float* accum_rgb, RtRenderStats* stats);
+/* The partition used: samples [*lo, *hi) of [sample_begin, sample_end) belong to `rank` of `world`; contiguous,
+ * disjoint, covering, sizes differing by at most one (the first (total mod world) ranks hold the larger share). */
+void rt_shard_samples(uint32_t sample_begin, uint32_t sample_end, uint32_t rank, uint32_t world, uint32_t* lo, uint32_t* hi);
+
 /* ---- tree construction on the device ------------------------------------- */
 
 #define RT_BVH_TOKEN_LEAF 0xFu          /* meta of a leaf token (not an RtNodeKind) */

@@ -20,6 +20,7 @@ ABI_SYMBOLS = (
     "rt_trace_records", "rt_trace_closest_device", "rt_trace_work", "rt_render", "rt_render_device", "rt_render_work",
     "rt_path_step", "rt_scene_profile", "rt_resolve_u8",
     "rt_resolve_u8_device", "rt_bvh_build", "rt_bvh_build_device", "rt_bvh_build_device_noalloc",
+    "rt_sharded_create", "rt_sharded_destroy", "rt_sharded_device_count", "rt_sharded_render", "rt_shard_samples",
 )
 HOST_SYMBOLS = (
     "rth_scene_build", "rth_scene_desc", "rth_scene_setup", "rth_scene_free", "rth_camera_new", "rth_builder_new",
@@ -89,9 +90,16 @@ class Library:
         L.rt_bvh_build.argtypes = [vp, u64, vp, P(C.c_double)]
         L.rt_bvh_build_device.argtypes = [vp, u64, vp, vp, vp, P(C.c_double)]
         L.rt_bvh_build_device_noalloc.argtypes = [vp, u64, vp, vp, vp]
+        L.rt_sharded_create.argtypes = [P(abi.RtSceneDesc), P(i), i, P(vp)]
+        L.rt_sharded_destroy.argtypes = [vp]
+        L.rt_sharded_destroy.restype = None
+        L.rt_sharded_device_count.argtypes = [vp]
+        L.rt_sharded_render.argtypes = [vp, P(abi.RtCamera), P(abi.RtRenderParams), vp, P(abi.RtRenderStats)]
+        L.rt_shard_samples.argtypes = [u32, u32, u32, u32, P(u32), P(u32)]
+        L.rt_shard_samples.restype = None
         for name in ABI_SYMBOLS:
             f = getattr(L, name)
-            if name not in ("rt_last_error", "rt_abi_version", "rt_scene_destroy"):
+            if name not in ("rt_last_error", "rt_abi_version", "rt_scene_destroy", "rt_sharded_destroy", "rt_shard_samples"):
                 f.restype = i
         if L.rt_abi_version() != abi.RT_ABI_VERSION:
             raise RtError("ABI version mismatch between librt_hip.so and raytracer_amd/abi.py")
@@ -246,6 +254,46 @@ class DeviceScene:
                                                   C.c_void_p(stream or 0), C.byref(st), work))
         w = list(work)
         return st, {"entries": w[0], **{abi.NODE_KINDS[k]: w[1 + k] for k in range(9)}}
+
+
+class ShardedScene:
+    """An RtShardedScene: one replica of the scene per GPU of this process, sample ranges sharded over them."""
+
+    def __init__(self, host_scene, devices=None, n_devices=0, lib=None):
+        self.lib = lib or host_scene.lib
+        self.h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices) if devices is not None else None
+        n = len(devices) if devices is not None else n_devices
+        self.lib.check(self.lib.lib.rt_sharded_create(C.byref(host_scene.desc), arr, n, C.byref(self.h)))
+
+    def device_count(self):
+        return self.lib.lib.rt_sharded_device_count(self.h)
+
+    def render(self, cam, params, accum=None):
+        if accum is None:
+            accum = np.zeros((params.height, params.width, 3), dtype=np.float32)
+        assert accum.dtype == np.float32 and accum.flags["C_CONTIGUOUS"]
+        st = abi.RtRenderStats()
+        self.lib.check(self.lib.lib.rt_sharded_render(self.h, C.byref(cam), C.byref(params), accum.ctypes.data, C.byref(st)))
+        return accum, st
+
+    def close(self):
+        if self.h:
+            self.lib.lib.rt_sharded_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_samples(lib, begin, end, rank, world):
+    """rt_shard_samples: the partition rt_sharded_render uses."""
+    lo, hi = C.c_uint32(), C.c_uint32()
+    lib.lib.rt_shard_samples(begin, end, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
 
 
 def make_params(width, height, s0, s1, background, seed=0x5EED, max_depth=50, samples_per_batch=0):

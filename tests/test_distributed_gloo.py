@@ -28,6 +28,21 @@ def test_shard_samples_partition():
         shard_samples(0, 8, 2, 2)
 
 
+def test_library_shards_like_the_python_side(rtlib):
+    # rt_shard_samples (what rt_sharded_render uses inside the library) and distributed.shard_samples (what bench.py and
+    # the command-line renderer use across processes) are the same partition
+    from raytracer_amd import lib
+    for begin, total in ((0, 0), (5, 1), (0, 7), (3, 8), (0, 1000), (100, 10000)):
+        for world in (1, 2, 3, 4, 8):
+            for r in range(world):
+                assert lib.shard_samples(rtlib, begin, begin + total, r, world) == shard_samples(begin, begin + total, r, world)
+    assert lib.shard_samples(rtlib, 4, 9, 3, 2) == (4, 4)  # a rank outside the world owns nothing
+    assert rtlib.lib.rt_sharded_create(None, None, 0, None) == -1
+    assert rtlib.lib.rt_sharded_render(None, None, None, None, None) == -1
+    assert rtlib.lib.rt_sharded_device_count(None) == 0
+    rtlib.lib.rt_sharded_destroy(None)
+
+
 def test_equal_batches_leave_no_runt():
     # BASELINE configs[3] on 8 GPUs: 10 000 spp / 8 = 1250 per GPU; with at most 1024 per batch that is 2 x 625, not 1024 + 226
     assert equal_batches(0, 1250, 1024) == [(0, 625), (625, 1250)]

@@ -306,3 +306,29 @@ def test_c5_ten_million_triangles_at_4k(gpu, orc):
     assert off.any(axis=2).mean() <= PIXEL_FRACTION, off.any(axis=2).mean()
     print("C5 full size: host scene %.1f s, oracle scene %.1f s, %d rays per 4-spp render" % (t_host, t_orc, sab.rays))
     ds.close(); hs.close(); orc.api.scene_free(osc)
+
+
+def test_sharded_render_through_the_c_abi(gpu, orc):
+    # rt_sharded_render on the devices this box has (one here: the scene replica, the per-device host thread and
+    # stream, the sample sharding and the RCCL all-reduce all run, over one rank): the same picture as rt_render,
+    # added onto what the caller's buffer held
+    hs, ds, osc, su, cam = setup_pair(gpu, orc, 9)
+    W = H = 96
+    bg = list(su.background)
+    p = lib.make_params(W, H, 3, 11, bg)
+    want, st0 = ds.render(cam, p)
+    sh = lib.ShardedScene(hs)
+    assert sh.device_count() == gpu.device_count()
+    start = np.full((H, W, 3), 0.25, dtype=np.float32)
+    got, st = sh.render(cam, p, accum=start.copy())
+    assert st.paths == st0.paths and st.rays == st0.rays
+    assert np.allclose(got, want + 0.25, rtol=2e-6, atol=1e-6)
+    one = lib.ShardedScene(hs, devices=[0])
+    got1, _ = one.render(cam, p)
+    assert np.array_equal(got1, want)  # one device: the same additions in the same order
+    with pytest.raises(lib.RtError):
+        lib.ShardedScene(hs, devices=[0, 0])
+    with pytest.raises(lib.RtError):
+        lib.ShardedScene(hs, devices=[gpu.device_count()])
+    sh.close(); one.close()
+    ds.close(); hs.close(); orc.api.scene_free(osc)
