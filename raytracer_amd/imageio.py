@@ -6,6 +6,7 @@ accumulation buffer can also be saved with the number of samples it holds, so th
 resume: samples are keyed by their index, so samples [0, a) + [a, b) give the same sums as [0, b) when the batch
 boundaries are the same."""
 import json
+import os
 import struct
 import zlib
 
@@ -71,8 +72,14 @@ def write_image(path, rgb):
 def save_checkpoint(path, accum, spp_done, meta):
     """accum: float32 [H, W, 3] sum over the first spp_done samples of every pixel; meta: what the sums depend on
     (scene, seed, size, batch size ...), compared on resume."""
-    with open(path, "wb") as f:
+    # written beside the target and moved into place: a run that is interrupted while saving leaves the previous
+    # checkpoint intact instead of a truncated file
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
         np.savez(f, accum=np.asarray(accum, dtype=np.float32), spp_done=np.int64(spp_done), meta=np.frombuffer(json.dumps(meta, sort_keys=True).encode(), dtype=np.uint8))
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, path)
 
 
 def load_checkpoint(path, meta):

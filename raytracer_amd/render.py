@@ -51,6 +51,10 @@ def plan(args, setup):
     spp = args.spp or int(setup.samples_per_pixel)
     if width < 2 or height < 2 or spp < 1:
         raise SystemExit("width and height must be at least 2 and spp at least 1")
+    if args.checkpoint and not args.spp_per_batch:
+        # the sums depend on where the batches are cut (f32 accumulation per batch); the library's own choice follows
+        # the free device memory of the moment, so a checkpointed render pins the batch size instead
+        args.spp_per_batch = max(1, min(1024, (512 << 20) // (width * height)))
     meta = {"scene": args.scene, "width": width, "height": height, "seed": args.seed, "max_depth": args.max_depth, "bvh": args.bvh,
             "shutter_bvh": bool(args.shutter_bvh), "triangles": args.triangles if args.scene == 12 else 0,
             "boxes_per_side": args.boxes_per_side, "spp_per_batch": args.spp_per_batch}

@@ -71,6 +71,11 @@ pub struct Flat {
     xf_stack: Vec<u32>,
     in_medium: bool,
     next_prim: u32, next_inst: u32, next_medium: u32,
+    /// box of the innermost BVHNode around the object being flattened, and whether some MovingSphere reaches
+    /// outside it during its motion (random_scene: tree over t in (0, 0.1), src/main.rs:315): the scene is then
+    /// flagged RT_DESC_BOXES_MAY_NOT_BOUND and the kernels run the per-axis box rule of src/aabb.rs:15-30
+    enclosing: Option<([f64; 3], [f64; 3])>,
+    pub boxes_may_not_bound: bool,
 }
 
 impl Flat {
@@ -108,7 +113,7 @@ impl Flat {
 
     pub fn desc(&self) -> RtSceneDesc {
         RtSceneDesc {
-            abi_version: RT_ABI_VERSION, _pad: 0,
+            abi_version: RT_ABI_VERSION, flags: if self.boxes_may_not_bound { RT_DESC_BOXES_MAY_NOT_BOUND } else { 0 },
             nodes: self.nodes.as_ptr(), n_nodes: self.nodes.len() as u64,
             spheres: self.spheres.as_ptr(), n_spheres: self.spheres.len() as u64,
             msphere: self.msphere.as_ptr(), n_msphere: self.msphere.len() as u64,
@@ -131,6 +136,12 @@ pub fn flatten_sphere(s: &Sphere, f: &mut Flat) {                           // s
     f.leaf(key(s), RT_N_SPHERE, |f| &mut f.spheres, |f| RtSphere { c: a3(&s.center), r: s.radius, mat: s.mat_ptr.describe(f), prim_id: f.prim_id() });
 }
 pub fn flatten_moving_sphere(s: &MovingSphere, f: &mut Flat) {              // :187-194
+    if let Some((mn, mx)) = f.enclosing {
+        for c in [&s.center0, &s.center1].iter() {                           // the ends of the motion bound all of it
+            let c = a3(c);
+            if (0..3).any(|a| c[a] - s.radius < mn[a] || c[a] + s.radius > mx[a]) { f.boxes_may_not_bound = true; }
+        }
+    }
     f.leaf(key(s), RT_N_MSPHERE, |f| &mut f.msphere, |f| RtMovingSphere {
         c0: a3(&s.center0), c1: a3(&s.center1), t0: s.time0, t1: s.time1, r: s.radius, mat: s.mat_ptr.describe(f), prim_id: f.prim_id() });
 }
@@ -157,8 +168,10 @@ pub fn flatten_bvh(n: &BVHNode, f: &mut Flat) {                             // s
         f.nodes[at].lo[a] = if flat { f32::INFINITY } else { f32_down(mn[a]) };
         f.nodes[at].hi[a] = if flat { f32::NEG_INFINITY } else { f32_up(mx[a]) };
     }
+    let outer = f.enclosing.replace((mn, mx));
     n.left.flatten(f);
     if !Arc::ptr_eq(&n.left, &n.right) { n.right.flatten(f); }              // span-1 node holds one object twice (:39-44)
+    f.enclosing = outer;
     f.nodes[at].link = f.nodes.len() as u32;
 }
 /// A tree built by `rt_bvh_build` on the GPU instead of `BVHNode::new` (src/bvh.rs:17-98): the object list and the

@@ -103,3 +103,31 @@ def test_cli_tree_options_give_the_same_picture(gpu, tmp_path):
     for tree in ("widest", "lbvh"):
         differs = (pics[tree] != pics["reference"]).any(axis=2)
         assert differs.mean() < 0.01, "%s: %d pixels differ" % (tree, differs.sum())
+
+
+def test_checkpoint_write_is_atomic(tmp_path, monkeypatch):
+    # a save that dies half way must leave the previous checkpoint readable
+    path = str(tmp_path / "ck.npz")
+    meta = {"scene": 7, "seed": 1}
+    first = np.full((4, 5, 3), 2.0, dtype=np.float32)
+    imageio.save_checkpoint(path, first, 8, meta)
+
+    def dying_savez(f, **kw):
+        f.write(b"PK\x03\x04 truncated")
+        raise KeyboardInterrupt
+
+    monkeypatch.setattr(np, "savez", dying_savez)
+    with pytest.raises(KeyboardInterrupt):
+        imageio.save_checkpoint(path, first * 2, 16, meta)
+    monkeypatch.undo()
+    accum, done = imageio.load_checkpoint(path, meta)
+    assert done == 8 and np.array_equal(accum, first)
+
+
+def test_checkpointed_renders_pin_the_batch_size(rtlib):
+    su = rtlib.host.scene_setup(9)
+    args = render.parse_args(["--scene", "9", "--checkpoint", "x.npz"])
+    _, _, _, meta = render.plan(args, su)
+    assert meta["spp_per_batch"] == 838 == (512 << 20) // (800 * 800)  # fixed by the image size, not by free memory
+    args = render.parse_args(["--scene", "9"])
+    assert render.plan(args, su)[3]["spp_per_batch"] == 0  # without a checkpoint the library sizes batches itself

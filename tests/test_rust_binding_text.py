@@ -1,0 +1,127 @@
+"""The Rust declarations a maintainer of the reference would bind (rust/raytracer-hip-sys/src/lib.rs) cannot be
+compiled here (no cargo / rustc in the image), so their text is held to the C header instead: every struct of
+include/rt/abi.h must appear with the same fields in the same order and of the matching type, every function with
+the same parameters and return type, and nothing may be declared on the Rust side that the header does not have."""
+import os
+import re
+
+from conftest import ROOT
+
+C2RUST = {"uint8_t": "u8", "uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "float": "f32", "double": "f64", "int": "c_int",
+          "char": "c_char", "void": "c_void"}
+
+
+def strip_comments(text):
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
+def c_structs(text):
+    out = {}
+    for body, name in re.findall(r"typedef struct \w+ \{(.*?)\} (\w+);", text, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r"(const )?(\w+)\s*(\*?)\s*(.*)", decl)
+            const, ctype, star, names = m.groups()
+            for nm in names.split(","):
+                nm = nm.strip()
+                dims = [int(d) for d in re.findall(r"\[(\d+)\]", nm)]
+                nm = nm.split("[")[0].strip()
+                ptr = star
+                if nm.startswith("*"):
+                    ptr, nm = "*", nm[1:].strip()
+                rt = C2RUST.get(ctype, ctype)
+                for d in reversed(dims):
+                    rt = "[%s; %d]" % (rt, d)
+                if ptr:
+                    rt = ("*const " if const else "*mut ") + rt
+                fields.append((nm, rt))
+        out[name] = fields
+    return out
+
+
+def c_type_to_rust(t):
+    t = " ".join(t.replace("*", " * ").split())
+    const = t.startswith("const ")
+    if const:
+        t = t[6:]
+    parts = t.split()
+    base = C2RUST.get(parts[0], parts[0])
+    stars = parts.count("*")
+    if stars == 0:
+        return base
+    r = ("*const " if const else "*mut ") + base
+    for _ in range(stars - 1):
+        r = "*mut " + r
+    return r
+
+
+def c_functions(text):
+    out = {}
+    for ret, name, args in re.findall(r"^\s*((?:const )?\w+\s*\*?)\s*(rt_\w+)\s*\(([^)]*)\)\s*;", text, flags=re.M):
+        params = []
+        if args.strip() != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                m = re.match(r"(.*?)(\w+)$", a)
+                params.append((m.group(2), c_type_to_rust(m.group(1))))
+        out[name] = (params, None if ret.strip() == "void" else c_type_to_rust(ret))
+    return out
+
+
+def rust_structs(text):
+    out = {}
+    for name, body in re.findall(r"pub struct (\w+)\s*\{(.*?)\}", text, flags=re.S):
+        fields = []
+        depth, cur = 0, ""
+        for ch in body + ",":
+            if ch in "[<(":
+                depth += 1
+            if ch in "]>)":
+                depth -= 1
+            if ch == "," and depth == 0:
+                cur = cur.strip()
+                if cur:
+                    nm, ty = cur.replace("pub ", "", 1).split(":", 1)
+                    fields.append((nm.strip(), " ".join(ty.split())))
+                cur = ""
+            else:
+                cur += ch
+        out[name] = fields
+    return out
+
+
+def rust_functions(text):
+    out = {}
+    for name, args, ret in re.findall(r"pub fn (rt_\w+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;", text):
+        params = []
+        for a in args.split(","):
+            a = a.strip()
+            if a:
+                nm, ty = a.split(":", 1)
+                params.append((nm.strip(), " ".join(ty.split())))
+        out[name] = (params, ret.strip() if ret else None)
+    return out
+
+
+def test_rust_declarations_match_the_header():
+    header = strip_comments(open(os.path.join(ROOT, "include", "rt", "abi.h")).read())
+    rust = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "rust", "raytracer-hip-sys", "src", "lib.rs")).read())
+    cs, rs = c_structs(header), rust_structs(rust)
+    assert set(cs) == set(rs), (sorted(set(cs) - set(rs)), sorted(set(rs) - set(cs)))
+    for name in cs:
+        assert cs[name] == rs[name], (name, cs[name], rs[name])
+    cf, rf = c_functions(header), rust_functions(rust)
+    assert set(cf) == set(rf), (sorted(set(cf) - set(rf)), sorted(set(rf) - set(cf)))
+    for name in cf:
+        assert cf[name] == rf[name], (name, cf[name], rf[name])
+    assert len(cf) >= 24 and len(cs) >= 21
+    # constants both sides name
+    for cname, pattern in (("RT_BVH_TOKEN_LEAF", r"RT_BVH_TOKEN_LEAF 0xFu"), ("RT_BVH_NOALLOC_MAX_OBJECTS", r"RT_BVH_NOALLOC_MAX_OBJECTS 65536u"),
+                           ("RT_DESC_BOXES_MAY_NOT_BOUND", r"RT_DESC_BOXES_MAY_NOT_BOUND 1u")):
+        assert re.search(pattern, header) and cname in rust, cname
+    # the opaque handles
+    for h in ("RtScene", "RtShardedScene"):
+        assert re.search(r"typedef struct %s %s;" % (h, h), header) and re.search(r"pub enum %s \{\}" % h, rust)
