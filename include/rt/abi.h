@@ -320,6 +320,24 @@ int rt_bvh_build(const double* boxes, uint64_t n, RtNode* tokens_out, double* ms
  * meaningless) and 0 otherwise. */
 int rt_bvh_build_device(const double* boxes_dev, uint64_t n, RtNode* tokens_dev, uint32_t* flag_dev, void* stream, double* ms_device);
 
+/* Turns the tokens of rt_bvh_build_device into the entry stream of RtSceneDesc.nodes on the device: every leaf
+ * token is replaced by the stream entries of its object and the links are translated (what the caller of
+ * rt_bvh_build does on the host). obj_entries_dev: the entries of all objects, object after object, as a flattener
+ * emits them when each object is flattened on its own (links of RT_N_INNER / RT_N_MEDIUM entries index into this
+ * array); obj_offsets_dev: n + 1 offsets into it (object i owns [offsets[i], offsets[i + 1])); out_dev: room for
+ * n_entries_out = (n - 1) + offsets[n] entries (checked). Waits for completion. */
+int rt_bvh_expand_device(const RtNode* tokens_dev, uint64_t n, const RtNode* obj_entries_dev, const uint32_t* obj_offsets_dev,
+                         uint64_t n_entries_out, RtNode* out_dev, void* stream);
+/* rt_bvh_build + rt_bvh_expand_device with host buffers in and out; the tokens never leave the device.
+ * out: room for (n - 1) + obj_offsets[n] entries. */
+int rt_bvh_build_stream(const double* boxes, uint64_t n, const RtNode* obj_entries, const uint32_t* obj_offsets, RtNode* out, double* ms_device);
+/* Refits a built tree to moved objects (BVHNode::new, src/bvh.rs:80-88, computes a node's box from its children's;
+ * this recomputes those boxes over the topology the tokens hold): every inner token of tokens_dev (2 n - 1 tokens as
+ * rt_bvh_build_device wrote them) gets the box of the leaves under it, taken from boxes_dev (n x 6 doubles, indexed by
+ * the leaf tokens' object numbers), rounded outward to f32; links and leaf tokens stay. The result is bit for bit
+ * what rt_bvh_build_device writes when the boxes still sort into the same order. flag_dev as there. Waits. */
+int rt_bvh_refit_device(RtNode* tokens_dev, uint64_t n, const double* boxes_dev, uint32_t* flag_dev, void* stream);
+
 #define RT_BVH_NOALLOC_MAX_OBJECTS 65536u
 #define RT_BVH_NOALLOC_SCRATCH_BYTES (16u << 20)
 /* rt_bvh_build_device for callers that cannot allocate: code under HIP graph capture, tight per-frame rebuild

@@ -21,6 +21,7 @@
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "../../include/rt/abi.h"
 #include "host/errors.hpp"
@@ -387,7 +388,7 @@ int enqueue_build(const double* d_boxes, uint32_t n, RtNode* d_tokens, uint32_t*
 }
 
 struct DeviceBuffers {  // freed on every way out
-    void* p[4] = {};
+    void* p[8] = {};
     int used = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ~DeviceBuffers() {
@@ -440,6 +441,188 @@ extern "C" int rt_bvh_build_device(const double* boxes_dev, uint64_t n64, RtNode
         BVH_TRY(hipEventElapsedTime(&ms, mem.e0, mem.e1));
         *ms_device = ms;
     }
+    return RT_OK;
+}
+
+// ---- tokens -> entry stream, and refitting the boxes of a built tree ------------------------------------------
+namespace bvh {
+
+// how many stream entries token k turns into: an inner token is one entry, a leaf token the entries of its object
+__global__ __launch_bounds__(BLOCK) void k_token_sizes(const RtNode* __restrict__ tokens, uint32_t n_tokens, const uint32_t* __restrict__ obj_offsets,
+                                                       uint32_t* __restrict__ sizes) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k > n_tokens) return;
+    uint32_t sz = 0u;  // sizes[n_tokens] = 0: the scan then leaves the total there
+    if (k < n_tokens) {
+        const RtNode t = tokens[k];
+        sz = t.meta == RT_BVH_TOKEN_LEAF ? obj_offsets[t.link + 1u] - obj_offsets[t.link] : 1u;
+    }
+    sizes[k] = sz;
+}
+
+// pos = exclusive prefix sum of the sizes. Inner token: the entry with its link translated; leaf token: the object's
+// entries, links of box and medium entries (the only kinds that carry one) moved from the object's own range to where
+// the entries now stand.
+__global__ __launch_bounds__(BLOCK) void k_expand(const RtNode* __restrict__ tokens, uint32_t n_tokens, const uint32_t* __restrict__ pos,
+                                                  const RtNode* __restrict__ obj_entries, const uint32_t* __restrict__ obj_offsets,
+                                                  RtNode* __restrict__ out) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n_tokens) return;
+    RtNode t = tokens[k];
+    const uint32_t at = pos[k];
+    if (t.meta != RT_BVH_TOKEN_LEAF) {
+        t.link = pos[t.link];
+        out[at] = t;
+        return;
+    }
+    const uint32_t first = obj_offsets[t.link], last = obj_offsets[t.link + 1u];
+    for (uint32_t e = first; e < last; ++e) {
+        RtNode x = obj_entries[e];
+        const uint32_t kind = x.meta & 15u;
+        if (kind == RT_N_INNER || kind == RT_N_MEDIUM) x.link = x.link - first + at;
+        out[at + (e - first)] = x;
+    }
+}
+
+// refit: leaf rank (position among the leaves, which is the sorted position the tree was built over) per token
+__global__ __launch_bounds__(BLOCK) void k_leaf_flags(const RtNode* __restrict__ tokens, uint32_t n_tokens, uint32_t* __restrict__ flags) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k > n_tokens) return;
+    flags[k] = (k < n_tokens && tokens[k].meta == RT_BVH_TOKEN_LEAF) ? 1u : 0u;
+}
+__global__ __launch_bounds__(BLOCK) void k_rank_objects(const RtNode* __restrict__ tokens, uint32_t n_tokens, const uint32_t* __restrict__ rank,
+                                                        uint32_t* __restrict__ object, uint32_t n_objects, uint32_t* __restrict__ bad) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n_tokens) return;
+    const RtNode t = tokens[k];
+    if (t.meta != RT_BVH_TOKEN_LEAF) return;
+    if (t.link >= n_objects) { *bad = 1u; return; }
+    object[rank[k]] = t.link;
+}
+__global__ __launch_bounds__(BLOCK) void k_refit(Tree t, const double* __restrict__ boxes, RtNode* __restrict__ tokens, uint32_t n_tokens,
+                                                 const uint32_t* __restrict__ rank) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n_tokens) return;
+    RtNode x = tokens[k];
+    if (x.meta == RT_BVH_TOKEN_LEAF || x.link > n_tokens || x.link <= k) return;
+    const uint32_t first = rank[k], past = rank[x.link];  // leaves under an inner token: those between it and its link
+    if (past <= first || past > t.n) return;
+    const Box6d box = past - first == 1u ? load_box(boxes, t.object[first]) : range_box(t, boxes, first, past - 1u);
+    const double* b = box.v;
+    const bool flat = b[0] == b[3] || b[1] == b[4] || b[2] == b[5];
+    for (int a = 0; a < 3; ++a) {
+        x.lo[a] = flat ? INFINITY : f32_down(b[a]);
+        x.hi[a] = flat ? -INFINITY : f32_up(b[3 + a]);
+    }
+    tokens[k] = x;
+}
+
+int scan_temp_bytes(uint32_t n, size_t* bytes) {
+    *bytes = 0;
+    BVH_TRY(rocprim::exclusive_scan(nullptr, *bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n, rocprim::plus<uint32_t>(), (hipStream_t) nullptr));
+    return RT_OK;
+}
+
+}  // namespace bvh
+
+extern "C" int rt_bvh_expand_device(const RtNode* tokens_dev, uint64_t n_objects, const RtNode* obj_entries_dev, const uint32_t* obj_offsets_dev,
+                                    uint64_t n_entries_out, RtNode* out_dev, void* stream) {
+    using namespace bvh;
+    if (!tokens_dev || !obj_entries_dev || !obj_offsets_dev || !out_dev) return rt::set_error(RT_E_INVALID, "null argument");
+    if (int rc = check_count(n_objects)) return rc;
+    if (n_entries_out >= 0xFFFFFFFFull) return rt::set_error(RT_E_INVALID, "too many entries");
+    const uint32_t n_tokens = (uint32_t)(2 * n_objects - 1);
+    size_t scan_bytes = 0;
+    if (int rc = scan_temp_bytes(n_tokens + 1u, &scan_bytes)) return rc;
+    DeviceBuffers mem;
+    void *d_sizes = nullptr, *d_pos = nullptr, *d_tmp = nullptr;
+    BVH_TRY(mem.get(&d_sizes, (size_t)(n_tokens + 1u) * sizeof(uint32_t)));
+    BVH_TRY(mem.get(&d_pos, (size_t)(n_tokens + 1u) * sizeof(uint32_t)));
+    BVH_TRY(mem.get(&d_tmp, scan_bytes));
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t grid = (n_tokens + 1u + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(k_token_sizes, dim3(grid), dim3(BLOCK), 0, st, tokens_dev, n_tokens, obj_offsets_dev, (uint32_t*)d_sizes);
+    BVH_TRY(hipGetLastError());
+    BVH_TRY(rocprim::exclusive_scan(d_tmp, scan_bytes, (uint32_t*)d_sizes, (uint32_t*)d_pos, 0u, (size_t)n_tokens + 1u, rocprim::plus<uint32_t>(), st));
+    uint32_t total = 0;
+    BVH_TRY(hipMemcpyAsync(&total, (uint32_t*)d_pos + n_tokens, sizeof total, hipMemcpyDeviceToHost, st));
+    BVH_TRY(hipStreamSynchronize(st));
+    if (total != n_entries_out)
+        return rt::set_error(RT_E_INVALID, "the tokens expand to " + std::to_string(total) + " entries, the caller expects " + std::to_string(n_entries_out));
+    hipLaunchKernelGGL(k_expand, dim3(grid), dim3(BLOCK), 0, st, tokens_dev, n_tokens, (const uint32_t*)d_pos, obj_entries_dev, obj_offsets_dev, out_dev);
+    BVH_TRY(hipGetLastError());
+    BVH_TRY(hipStreamSynchronize(st));  // the scratch memory is released on return
+    return RT_OK;
+}
+
+extern "C" int rt_bvh_refit_device(RtNode* tokens_dev, uint64_t n_objects, const double* boxes_dev, uint32_t* flag_dev, void* stream) {
+    using namespace bvh;
+    if (!tokens_dev || !boxes_dev) return rt::set_error(RT_E_INVALID, "null argument");
+    if (int rc = check_count(n_objects)) return rc;
+    const uint32_t n = (uint32_t)n_objects, n_tokens = 2u * n - 1u;
+    size_t scan_bytes = 0;
+    if (int rc = scan_temp_bytes(n_tokens + 1u, &scan_bytes)) return rc;
+    Scratch m = carve(nullptr, n, scan_bytes);  // the same arrays as a build (the sort area holds the scan's temporary storage)
+    DeviceBuffers mem;
+    void *base = nullptr, *d_flags = nullptr, *d_rank = nullptr;
+    BVH_TRY(mem.get(&base, m.total));
+    BVH_TRY(mem.get(&d_flags, (size_t)(n_tokens + 1u) * sizeof(uint32_t)));
+    BVH_TRY(mem.get(&d_rank, (size_t)(n_tokens + 1u) * sizeof(uint32_t)));
+    m = carve(static_cast<char*>(base), n, scan_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t per_token = (n_tokens + 1u + BLOCK - 1) / BLOCK, per_leaf = (n + BLOCK - 1) / BLOCK;
+    BVH_TRY(hipMemsetAsync(m.bad, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_leaf_flags, dim3(per_token), dim3(BLOCK), 0, st, tokens_dev, n_tokens, (uint32_t*)d_flags);
+    BVH_TRY(hipGetLastError());
+    size_t sb = scan_bytes;
+    BVH_TRY(rocprim::exclusive_scan(m.sort, sb, (uint32_t*)d_flags, (uint32_t*)d_rank, 0u, (size_t)n_tokens + 1u, rocprim::plus<uint32_t>(), st));
+    hipLaunchKernelGGL(k_rank_objects, dim3(per_token), dim3(BLOCK), 0, st, tokens_dev, n_tokens, (const uint32_t*)d_rank, m.obj, n, m.bad);
+    hipLaunchKernelGGL(k_centre_bounds, dim3(m.reduce_blocks), dim3(BLOCK), 0, st, boxes_dev, n, m.partial, m.bad);  // only for its NaN check
+    Tree t{m.code, m.obj, m.parent_inner, m.parent_leaf, m.first, m.last, m.split, m.from_start, m.to_end, m.table, n, m.blocks};
+    hipLaunchKernelGGL(k_block_unions, dim3(per_leaf), dim3(BLOCK), 0, st, t, boxes_dev);
+    for (uint32_t k = 1; k < m.levels; ++k)
+        hipLaunchKernelGGL(k_table_level, dim3((m.blocks + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, t, k);
+    hipLaunchKernelGGL(k_refit, dim3(per_token), dim3(BLOCK), 0, st, t, boxes_dev, tokens_dev, n_tokens, (const uint32_t*)d_rank);
+    BVH_TRY(hipGetLastError());
+    if (flag_dev) BVH_TRY(hipMemcpyAsync(flag_dev, m.bad, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    BVH_TRY(hipStreamSynchronize(st));  // the scratch memory is released on return
+    return RT_OK;
+}
+
+// Host buffers in and out: the tree over `boxes` and its tokens turned into stream entries, without the tokens ever
+// leaving the device.
+extern "C" int rt_bvh_build_stream(const double* boxes, uint64_t n_objects, const RtNode* obj_entries, const uint32_t* obj_offsets,
+                                   RtNode* out, double* ms_device) {
+    using namespace bvh;
+    if (!boxes || !obj_entries || !obj_offsets || !out) return rt::set_error(RT_E_INVALID, "null argument");
+    if (int rc = check_count(n_objects)) return rc;
+    if (int rc = need_device()) return rc;
+    const uint32_t n = (uint32_t)n_objects;
+    const uint64_t n_obj_entries = obj_offsets[n];
+    const uint64_t n_out = (uint64_t)(n - 1u) + n_obj_entries;
+    if (obj_offsets[0] != 0u || n_out >= 0xFFFFFFFFull) return rt::set_error(RT_E_INVALID, "bad object offsets");
+    DeviceBuffers mem;
+    void *d_boxes = nullptr, *d_tokens = nullptr, *d_flag = nullptr, *d_entries = nullptr;
+    BVH_TRY(mem.get(&d_boxes, 6ull * n * sizeof(double)));
+    BVH_TRY(mem.get(&d_tokens, (2ull * n - 1) * sizeof(RtNode)));
+    BVH_TRY(mem.get(&d_flag, sizeof(uint32_t)));
+    BVH_TRY(mem.get(&d_entries, n_obj_entries * sizeof(RtNode) + (n + 1ull) * sizeof(uint32_t)));
+    uint32_t* d_offsets = reinterpret_cast<uint32_t*>(static_cast<RtNode*>(d_entries) + n_obj_entries);
+    BVH_TRY(hipMemcpy(d_boxes, boxes, 6ull * n * sizeof(double), hipMemcpyHostToDevice));
+    BVH_TRY(hipMemcpy(d_entries, obj_entries, n_obj_entries * sizeof(RtNode), hipMemcpyHostToDevice));
+    BVH_TRY(hipMemcpy(d_offsets, obj_offsets, (n + 1ull) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (int rc = rt_bvh_build_device(static_cast<const double*>(d_boxes), n_objects, static_cast<RtNode*>(d_tokens), static_cast<uint32_t*>(d_flag),
+                                     nullptr, ms_device))
+        return rc;
+    uint32_t bad = 0;
+    BVH_TRY(hipMemcpy(&bad, d_flag, sizeof(bad), hipMemcpyDeviceToHost));
+    if (bad) return rt::set_error(RT_E_INVALID, "a bounding box holds NaN or has no finite centre");
+    void* d_out = nullptr;
+    BVH_TRY(mem.get(&d_out, n_out * sizeof(RtNode)));
+    if (int rc = rt_bvh_expand_device(static_cast<const RtNode*>(d_tokens), n_objects, static_cast<const RtNode*>(d_entries), d_offsets, n_out,
+                                      static_cast<RtNode*>(d_out), nullptr))
+        return rc;
+    BVH_TRY(hipMemcpy(out, d_out, n_out * sizeof(RtNode), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -1,6 +1,9 @@
 // C entry points of include/rt/host.h: scene library, camera and the handle-based
 // builder. Exceptions thrown by the object model (the reference panics in the same
 // places: src/bvh.rs:86,124, src/vec3.rs:285-286) are turned into error codes here.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -96,9 +99,18 @@ int rth_scene_build(int scene_id, uint64_t seed, const RtSceneOptions* opt, RtHo
             TreePolicy(bool widest, bool device) { g_bvh_widest_axis = widest; g_bvh_device = device; }
             ~TreePolicy() { g_bvh_widest_axis = false; g_bvh_device = false; }
         } policy(o.bvh_widest_axis, opt && (opt->flags & RT_SCENE_BVH_LBVH) != 0);
+        const bool timing = std::getenv("RT_HOST_TIMING") != nullptr;  // developer knob: where scene construction spends its time
+        auto t0 = std::chrono::steady_clock::now();
         HitPtr world = build_scene(scene_id, o);
         if (!world) return rt::set_error(RT_E_INVALID, "unknown scene id");
+        auto t1 = std::chrono::steady_clock::now();
         *out = flatten_root(*world);
+        auto t2 = std::chrono::steady_clock::now();
+        world.reset();
+        auto t3 = std::chrono::steady_clock::now();
+        if (timing)
+            std::fprintf(stderr, "rth_scene_build: objects + tree %.3f s, flatten %.3f s, release %.3f s\n", std::chrono::duration<double>(t1 - t0).count(),
+                         std::chrono::duration<double>(t2 - t1).count(), std::chrono::duration<double>(t3 - t2).count());
         return RT_OK;
     });
 }

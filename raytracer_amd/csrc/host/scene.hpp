@@ -9,7 +9,10 @@
 // (src/bvh.rs:17-98) sorts and bounds with it.
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <limits>
@@ -101,7 +104,49 @@ inline float f32_up(double v) {
 }
 
 // ---- flat table builder ----------------------------------------------------
+// object address -> table index. Open addressing with linear probing: a 10 M-triangle scene makes 10 M insertions,
+// which cost seconds in a node-based map.
+class PtrIndexMap {
+    struct Slot { const void* key; uint32_t value; };
+    std::vector<Slot> slots_;
+    size_t used_ = 0;
+    static size_t hash(const void* p) { return (size_t)(((uint64_t)(uintptr_t)p >> 4) * 0x9E3779B97F4A7C15ull >> 20); }
+    Slot* probe(const void* key) {
+        const size_t mask = slots_.size() - 1;
+        size_t i = hash(key) & mask;
+        while (slots_[i].key && slots_[i].key != key) i = (i + 1) & mask;
+        return &slots_[i];
+    }
+    void grow() {
+        std::vector<Slot> old;
+        old.swap(slots_);
+        slots_.assign(old.empty() ? 1024 : old.size() * 4, Slot{nullptr, 0});
+        for (const Slot& s : old)
+            if (s.key) *probe(s.key) = s;
+    }
+
+public:
+    using iterator = Slot*;
+    struct Found { const void* first; uint32_t second; };
+    iterator end() { return nullptr; }
+    iterator find(const void* key) {
+        if (slots_.empty()) return nullptr;
+        Slot* s = probe(key);
+        return s->key ? s : nullptr;
+    }
+    uint32_t& operator[](const void* key) {
+        if ((used_ + 1) * 2 > slots_.size()) grow();
+        Slot* s = probe(key);
+        if (!s->key) { s->key = key; s->value = 0; ++used_; }
+        return s->value;
+    }
+    void clear() { std::vector<Slot>().swap(slots_); used_ = 0; }
+};
+
+inline std::atomic<uint64_t> g_flat_generation{0};
+
 struct Flat {
+    const uint64_t gen = ++g_flat_generation;  // tells this flattening apart from every other one (see Hittable)
     std::vector<RtNode> nodes;
     std::vector<RtSphere> spheres;
     std::vector<RtMovingSphere> msphere;
@@ -115,7 +160,7 @@ struct Flat {
     std::vector<RtPerlin> perlins;
     std::vector<RtImage> images;
     std::vector<uint8_t> texels;
-    std::unordered_map<const void*, uint32_t> seen;  // object -> table index, so shared objects are stored once
+    PtrIndexMap seen;  // object -> table index, so shared objects are stored once
     std::vector<uint32_t> xf_stack;
     bool in_medium = false;
     // the time interval every BVHNode around the object being flattened was built over (their intersection), and
@@ -144,7 +189,7 @@ struct SolidColor : Texture {  // src/texture.rs:12-26
     explicit SolidColor(Color c) : color_value(c) {}
     uint32_t describe(Flat& f) const override {
         auto it = f.seen.find(this);
-        if (it != f.seen.end()) return it->second;
+        if (it != f.seen.end()) return it->value;
         RtTexture t{};
         t.kind = RT_T_SOLID;
         put3(t.a, color_value);
@@ -158,7 +203,7 @@ struct CheckerTexture : Texture {  // src/texture.rs:28-51: even = c1, odd = c2
     CheckerTexture(Color c1, Color c2) : even(c1), odd(c2) {}
     uint32_t describe(Flat& f) const override {
         auto it = f.seen.find(this);
-        if (it != f.seen.end()) return it->second;
+        if (it != f.seen.end()) return it->value;
         RtTexture t{};
         t.kind = RT_T_CHECKER;
         put3(t.a, even);
@@ -195,7 +240,7 @@ struct NoiseTexture : Texture {  // src/texture.rs:53-73
     explicit NoiseTexture(double sc) : noise(), scale(sc) {}
     uint32_t describe(Flat& f) const override {
         auto it = f.seen.find(this);
-        if (it != f.seen.end()) return it->second;
+        if (it != f.seen.end()) return it->value;
         f.perlins.push_back(noise.tab);
         RtTexture t{};
         t.kind = RT_T_NOISE;
@@ -214,7 +259,7 @@ struct ImageTexture : Texture {  // src/texture.rs:75-90; takes decoded RGB8 row
     }
     uint32_t describe(Flat& f) const override {
         auto it = f.seen.find(this);
-        if (it != f.seen.end()) return it->second;
+        if (it != f.seen.end()) return it->value;
         RtImage im{};
         im.width = width;
         im.height = height;
@@ -234,7 +279,7 @@ struct Material {
     virtual RtMaterial fill(Flat& f) const = 0;
     uint32_t describe(Flat& f) const {
         auto it = f.seen.find(this);
-        if (it != f.seen.end()) return it->second;
+        if (it != f.seen.end()) return it->value;
         RtMaterial m = fill(f);
         f.materials.push_back(m);
         return f.seen[this] = (uint32_t)f.materials.size() - 1;
@@ -276,6 +321,15 @@ struct Hittable {
     virtual ~Hittable() = default;
     virtual bool bounding_box(double t0, double t1, AABB& out) const = 0;
     virtual void flatten(Flat& f) const = 0;
+
+protected:
+    // Where this object's row went in the flattening under way, so that an object reached twice (shared Arc in the
+    // reference) is stored once. Kept in the object instead of a map keyed by address: with 10 M triangles the map is
+    // half a gigabyte of randomly accessed memory and costs seconds. One flattening at a time per object.
+    mutable uint64_t flat_gen_ = 0;
+    mutable uint32_t flat_idx_ = 0;
+    bool flat_lookup(const Flat& f, uint32_t& idx) const { idx = flat_idx_; return flat_gen_ == f.gen; }
+    uint32_t flat_store(const Flat& f, uint32_t idx) const { flat_gen_ = f.gen; flat_idx_ = idx; return idx; }
 };
 using HitPtr = std::shared_ptr<Hittable>;
 
@@ -291,14 +345,12 @@ struct Sphere : Hittable {  // src/hittable.rs:48-62, 115-121
         return true;
     }
     void flatten(Flat& f) const override {
-        auto it = f.seen.find(this);
         uint32_t idx;
-        if (it != f.seen.end()) idx = it->second;
-        else {
+        if (!flat_lookup(f, idx)) {
             RtSphere s{};
             put3(s.c, center); s.r = radius; s.mat = mat_ptr->describe(f); s.prim_id = id;
             f.spheres.push_back(s);
-            idx = f.seen[this] = (uint32_t)f.spheres.size() - 1;
+            idx = flat_store(f, (uint32_t)f.spheres.size() - 1);
         }
         f.push_node(RT_N_SPHERE, idx);
     }
@@ -323,15 +375,13 @@ struct MovingSphere : Hittable {  // src/hittable.rs:187-212, 248-259
         // MovingSphere::bounding_box(t0, t1) bounds the sphere for times in [t0, t1] only (src/hittable.rs:248-259)
         const bool moves = center0.x != center1.x || center0.y != center1.y || center0.z != center1.z;
         if (moves && (std::fmin(time0, time1) < f.cover_t0 || std::fmax(time0, time1) > f.cover_t1)) f.boxes_may_not_bound = true;
-        auto it = f.seen.find(this);
         uint32_t idx;
-        if (it != f.seen.end()) idx = it->second;
-        else {
+        if (!flat_lookup(f, idx)) {
             RtMovingSphere s{};
             put3(s.c0, center0); put3(s.c1, center1); s.t0 = time0; s.t1 = time1; s.r = radius;
             s.mat = mat_ptr->describe(f); s.prim_id = id;
             f.msphere.push_back(s);
-            idx = f.seen[this] = (uint32_t)f.msphere.size() - 1;
+            idx = flat_store(f, (uint32_t)f.msphere.size() - 1);
         }
         f.push_node(RT_N_MSPHERE, idx);
     }
@@ -352,14 +402,12 @@ struct AARect : Hittable {
         return true;
     }
     void flatten(Flat& f) const override {
-        auto it = f.seen.find(this);
         uint32_t idx;
-        if (it != f.seen.end()) idx = it->second;
-        else {
+        if (!flat_lookup(f, idx)) {
             RtRect r{};
             r.a0 = a0; r.a1 = a1; r.b0 = b0; r.b1 = b1; r.k = k; r.axis = (uint32_t)axis; r.mat = mp->describe(f); r.prim_id = id;
             f.rects.push_back(r);
-            idx = f.seen[this] = (uint32_t)f.rects.size() - 1;
+            idx = flat_store(f, (uint32_t)f.rects.size() - 1);
         }
         f.push_node(RT_N_RECT, idx);
     }
@@ -375,14 +423,12 @@ struct Box6 : Hittable {  // src/box6.rs:9-85; the six rects of :22-71 are impli
     Box6(Point p0, Point p1, MatPtr m) : box_min(p0), box_max(p1), mat(std::move(m)), id(ctx().next_prim++) {}
     bool bounding_box(double, double, AABB& out) const override { out._min = box_min; out._max = box_max; return true; }
     void flatten(Flat& f) const override {
-        auto it = f.seen.find(this);
         uint32_t idx;
-        if (it != f.seen.end()) idx = it->second;
-        else {
+        if (!flat_lookup(f, idx)) {
             RtBox6 b{};
             put3(b.p0, box_min); put3(b.p1, box_max); b.mat = mat->describe(f); b.prim_id = id;
             f.boxes.push_back(b);
-            idx = f.seen[this] = (uint32_t)f.boxes.size() - 1;
+            idx = flat_store(f, (uint32_t)f.boxes.size() - 1);
         }
         f.push_node(RT_N_BOX6, idx);
     }
@@ -401,17 +447,15 @@ struct Triangle : Hittable {  // src/triangle.rs:7-23, 70-83 (argument order poi
         return true;
     }
     void flatten(Flat& f) const override {
-        auto it = f.seen.find(this);
         uint32_t idx;
-        if (it != f.seen.end()) idx = it->second;
-        else {
+        if (!flat_lookup(f, idx)) {
             RtTriangle t{};
             put3(t.p0, point0);
             put3(t.e1, point1 - point0);  // edge1, src/triangle.rs:27
             put3(t.e2, point2 - point0);  // edge2, :28
             t.mat = mp->describe(f); t.prim_id = id;
             f.triangles.push_back(t);
-            idx = f.seen[this] = (uint32_t)f.triangles.size() - 1;
+            idx = flat_store(f, (uint32_t)f.triangles.size() - 1);
         }
         f.push_node(RT_N_TRIANGLE, idx);
     }
@@ -523,14 +567,12 @@ struct ConstantMedium : Hittable {  // src/constant_medium.rs:10-31, 91-93
     void flatten(Flat& f) const override {
         if (f.in_medium) throw std::invalid_argument("a ConstantMedium inside the boundary of another is not supported");
         if (rng_id >= 0xFFF0u) throw std::length_error("too many ConstantMedium objects");
-        auto it = f.seen.find(this);
         uint32_t idx;
-        if (it != f.seen.end()) idx = it->second;
-        else {
+        if (!flat_lookup(f, idx)) {
             RtMedium m{};
             m.neg_inv_density = neg_inv_density; m.mat = phase_function->describe(f); m.rng_id = rng_id; m.prim_id = id;
             f.media.push_back(m);
-            idx = f.seen[this] = (uint32_t)f.media.size() - 1;
+            idx = flat_store(f, (uint32_t)f.media.size() - 1);
         }
         const uint32_t at = f.push_node(RT_N_MEDIUM, idx);
         f.in_medium = true;
@@ -690,42 +732,71 @@ struct AbiError : std::runtime_error {
 // that rt_bvh_build makes on the current HIP device.
 inline thread_local bool g_bvh_device = false;
 
-struct DeviceBvh : BVHNode {  // left / right stay empty: the tree is held as pre-order tokens
+struct DeviceBvh : BVHNode {  // left / right stay empty: the tree is made on the device when the scene is flattened
     std::vector<HitPtr> objects;
-    std::vector<RtNode> tokens;
-    double ms_device = 0.0;
+    double t0 = 0.0, t1 = 0.0;
+    mutable double ms_device = 0.0;
 
-    DeviceBvh(const std::vector<HitPtr>& list, double time0, double time1) : objects(list) {
-        set_times(time0, time1);
-        std::vector<double> boxes(objects.size() * 6);
+    void boxes_of(std::vector<double>& boxes, AABB* whole) const {
+        boxes.resize(objects.size() * 6);
         for (size_t i = 0; i < objects.size(); ++i) {
             AABB b;
-            if (!objects[i]->bounding_box(time0, time1, b)) throw std::runtime_error("object without a bounding box in BVHNode::new");
+            if (!objects[i]->bounding_box(t0, t1, b)) throw std::runtime_error("object without a bounding box in BVHNode::new");
             for (int a = 0; a < 3; ++a) { boxes[6 * i + a] = b._min[a]; boxes[6 * i + 3 + a] = b._max[a]; }
-            _box = i ? surrounding_box(_box, b) : b;  // min / max are exact: the same box as the tree's root
+            if (whole) *whole = i ? surrounding_box(*whole, b) : b;  // min / max are exact: the same box as the tree's root
         }
-        tokens.resize(2 * objects.size() - 1);
-        const int rc = rt_bvh_build(boxes.data(), objects.size(), tokens.data(), &ms_device);
-        if (rc != RT_OK) throw AbiError(rc, rt_last_error());
     }
+    DeviceBvh(const std::vector<HitPtr>& list, double time0, double time1) : objects(list), t0(time0), t1(time1) {
+        set_times(time0, time1);
+        if (objects.size() < 2) throw std::invalid_argument("a tree built on the device needs at least two objects");
+        if (objects.size() > RT_BVH_MAX_OBJECTS) throw std::invalid_argument("too many objects for one tree");
+        std::vector<double> boxes;
+        boxes_of(boxes, &_box);
+        // what rt_bvh_build refuses is refused here, where the reference's BVHNode::new would run (src/bvh.rs:94)
+        for (size_t i = 0; i < objects.size(); ++i)
+            for (int a = 0; a < 3; ++a) {
+                const double mn = boxes[6 * i + a], mx = boxes[6 * i + 3 + a], c = (mn + mx) * 0.5;
+                if (mn != mn || mx != mx || c != c || std::isinf(c)) throw std::invalid_argument("a bounding box holds NaN or has no finite centre");
+            }
+        int n_dev = rt_device_count();
+        if (n_dev < 1) throw AbiError(RT_E_DEVICE, "building a tree on the device needs a HIP device; there is no CPU path");
+    }
+    // Every object is flattened on its own, in list order (the order they were created in: sequential memory), into
+    // a side array; the device builds the tree over the boxes and puts each object's entries where its leaf stands
+    // (rt_bvh_build_stream). A walk over the tokens on the host would visit the objects in Morton order, one cache
+    // miss per object: 2 s for 10 M triangles.
     void flatten(Flat& f) const override {
         CoverScope cover(f, time0, time1);
-        std::vector<std::pair<uint32_t, uint32_t>> open;  // (entry, token after its subtree)
-        for (size_t k = 0; k < tokens.size(); ++k) {
-            const RtNode& t = tokens[k];
-            if (t.meta == RT_BVH_TOKEN_LEAF) {
-                objects.at(t.link)->flatten(f);
-            } else {
-                const uint32_t at = f.push_node(RT_N_INNER, 0);
-                for (int a = 0; a < 3; ++a) { f.nodes[at].lo[a] = t.lo[a]; f.nodes[at].hi[a] = t.hi[a]; }
-                open.emplace_back(at, t.link);
+        std::vector<RtNode> mine;
+        mine.swap(f.nodes);  // the entries before this tree; f.nodes collects the objects' entries meanwhile
+        std::vector<uint32_t> offsets(objects.size() + 1);
+        try {
+            for (size_t i = 0; i < objects.size(); ++i) {
+                offsets[i] = (uint32_t)f.nodes.size();
+                objects[i]->flatten(f);
+                if (f.nodes.size() >= 0xFFFFFFFFull) throw std::length_error("too many entries");
             }
-            while (!open.empty() && open.back().second == k + 1) {
-                f.nodes[open.back().first].link = (uint32_t)f.nodes.size();
-                open.pop_back();
+        } catch (...) { mine.swap(f.nodes); throw; }
+        offsets[objects.size()] = (uint32_t)f.nodes.size();
+        std::vector<RtNode> obj_entries;
+        obj_entries.swap(f.nodes);
+        mine.swap(f.nodes);
+        std::vector<double> boxes;
+        boxes_of(boxes, nullptr);
+        const size_t base = f.nodes.size(), n_out = objects.size() - 1 + obj_entries.size();
+        if (base + n_out >= 0xFFFFFFFFull) throw std::length_error("too many entries");
+        f.nodes.resize(base + n_out);
+        const auto t_begin = std::chrono::steady_clock::now();
+        const int rc = rt_bvh_build_stream(boxes.data(), objects.size(), obj_entries.data(), offsets.data(), f.nodes.data() + base, &ms_device);
+        if (rc != RT_OK) throw AbiError(rc, rt_last_error());
+        if (std::getenv("RT_HOST_TIMING"))
+            std::fprintf(stderr, "DeviceBvh: %zu objects, rt_bvh_build_stream %.3f s (tree on the device %.2f ms)\n", objects.size(),
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), ms_device);
+        if (base)  // links of the new entries count from where this tree starts
+            for (size_t k = base; k < f.nodes.size(); ++k) {
+                const uint32_t kind = f.nodes[k].meta & 15u;
+                if (kind == RT_N_INNER || kind == RT_N_MEDIUM) f.nodes[k].link += (uint32_t)base;
             }
-        }
-        if (!open.empty()) throw std::runtime_error("malformed tree tokens");
     }
 };
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -526,6 +527,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
 #undef RT_OCC
         if (oe != hipSuccess || per_cu < 1) per_cu = 1;
         s->grid_extend = s->n_cus * (uint32_t)per_cu;
+        if (const char* e = std::getenv("RT_EXTEND_CUS")) s->grid_extend = (uint32_t)std::max(1, std::atoi(e)) * (uint32_t)per_cu;  // developer knob
         int shade_per_cu = 0;
         if (s->shade_sort)
             oe = s->shade_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, rtd::k_shade<true, true>, rtd::SHADE_BLOCK, s->lds_bytes_shade)
@@ -538,6 +540,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
 #define RT_SHADE_GRID_MULT 1
 #endif
         s->grid_shade = s->n_cus * (uint32_t)shade_per_cu * RT_SHADE_GRID_MULT;
+        if (const char* e = std::getenv("RT_SHADE_CUS")) s->grid_shade = (uint32_t)std::max(1, std::atoi(e)) * (uint32_t)shade_per_cu;  // developer knob
         if ((rc = upload(s, d->nodes, d->n_nodes, &s->S.nodes))) break;
         if ((rc = upload(s, d->spheres, d->n_spheres, &s->S.spheres))) break;
         if ((rc = upload(s, d->msphere, d->n_msphere, &s->S.msphere))) break;

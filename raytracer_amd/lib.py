@@ -19,7 +19,8 @@ ABI_SYMBOLS = (
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_trace_closest",
     "rt_trace_records", "rt_trace_closest_device", "rt_trace_work", "rt_render", "rt_render_device", "rt_render_work",
     "rt_path_step", "rt_scene_profile", "rt_resolve_u8",
-    "rt_resolve_u8_device", "rt_bvh_build", "rt_bvh_build_device", "rt_bvh_build_device_noalloc",
+    "rt_resolve_u8_device", "rt_bvh_build", "rt_bvh_build_device", "rt_bvh_build_device_noalloc", "rt_bvh_expand_device", "rt_bvh_build_stream",
+    "rt_bvh_refit_device",
     "rt_sharded_create", "rt_sharded_destroy", "rt_sharded_device_count", "rt_sharded_render", "rt_shard_samples",
 )
 HOST_SYMBOLS = (
@@ -90,6 +91,9 @@ class Library:
         L.rt_bvh_build.argtypes = [vp, u64, vp, P(C.c_double)]
         L.rt_bvh_build_device.argtypes = [vp, u64, vp, vp, vp, P(C.c_double)]
         L.rt_bvh_build_device_noalloc.argtypes = [vp, u64, vp, vp, vp]
+        L.rt_bvh_expand_device.argtypes = [vp, u64, vp, vp, u64, vp, vp]
+        L.rt_bvh_build_stream.argtypes = [vp, u64, vp, vp, vp, P(C.c_double)]
+        L.rt_bvh_refit_device.argtypes = [vp, u64, vp, vp, vp]
         L.rt_sharded_create.argtypes = [P(abi.RtSceneDesc), P(i), i, P(vp)]
         L.rt_sharded_destroy.argtypes = [vp]
         L.rt_sharded_destroy.restype = None

@@ -67,6 +67,9 @@ extern "C" {
     /// boxes: n x 6 f64 (min xyz, max xyz); tokens_out: 2 n - 1 records in pre-order (leaf: meta == RT_BVH_TOKEN_LEAF, link = object)
     pub fn rt_bvh_build(boxes: *const f64, n: u64, tokens_out: *mut RtNode, ms_device: *mut f64) -> c_int;
     pub fn rt_bvh_build_device(boxes_dev: *const f64, n: u64, tokens_dev: *mut RtNode, flag_dev: *mut u32, stream: *mut c_void, ms_device: *mut f64) -> c_int;
+    pub fn rt_bvh_expand_device(tokens_dev: *const RtNode, n: u64, obj_entries_dev: *const RtNode, obj_offsets_dev: *const u32, n_entries_out: u64, out_dev: *mut RtNode, stream: *mut c_void) -> c_int;
+    pub fn rt_bvh_build_stream(boxes: *const f64, n: u64, obj_entries: *const RtNode, obj_offsets: *const u32, out: *mut RtNode, ms_device: *mut f64) -> c_int;
+    pub fn rt_bvh_refit_device(tokens_dev: *mut RtNode, n: u64, boxes_dev: *const f64, flag_dev: *mut u32, stream: *mut c_void) -> c_int;
     /// the same without any allocation: scratch memory in a static device array, at most RT_BVH_NOALLOC_MAX_OBJECTS objects
     pub fn rt_bvh_build_device_noalloc(boxes_dev: *const f64, n: u64, tokens_dev: *mut RtNode, flag_dev: *mut u32, stream: *mut c_void) -> c_int;
     /// one replica of the scene per GPU of this process; device i renders rt_shard_samples(.., i, G) of every pixel, one RCCL all-reduce

@@ -169,3 +169,107 @@ def test_device_resident_build_equals_the_host_buffer_build(gpu, orc, n):
         bad[1, 4] = np.nan
         _, flag3 = build_on_device(gpu, bad)
         assert flag3 == 1
+
+
+def f32_outward(lo, hi):
+    """f64 box -> f32 box rounded outward, as the builders store it."""
+    l = lo.astype(np.float32)
+    l = np.where(l.astype(np.float64) > lo, np.nextafter(l, np.float32(-np.inf)), l)
+    h = hi.astype(np.float32)
+    h = np.where(h.astype(np.float64) < hi, np.nextafter(h, np.float32(np.inf)), h)
+    return l, h
+
+
+def object_entries(n):
+    """Entries of n made-up objects as a flattener would emit them one by one: a primitive (1 entry), a wrapped
+    primitive (3), a medium around a sphere (2, the medium entry carrying a link)."""
+    entries, offsets = [], [0]
+    for i in range(n):
+        at = len(entries)
+        if i % 3 == 0:
+            entries.append((5 | (i << 4), 0))
+        elif i % 3 == 1:
+            entries += [(6 | (i << 4), 0), (4 | (i << 4), 0), (7 | (i << 4), 0)]
+        else:
+            entries += [(8 | (i << 4), at + 2), (1 | (i << 4), 0)]
+        offsets.append(len(entries))
+    arr = np.zeros(len(entries), dtype=abi.NODE_DTYPE)
+    arr["meta"] = [e[0] for e in entries]
+    arr["link"] = [e[1] for e in entries]
+    return arr, np.asarray(offsets, dtype=np.uint32)
+
+
+@pytest.mark.parametrize("n", [2, 3, 700, 20_000])
+def test_tokens_expanded_on_the_device(gpu, n):
+    # rt_bvh_build_stream against the expansion a host would do from the tokens of rt_bvh_build
+    import ctypes as C
+    rng = np.random.default_rng(n)
+    c = rng.normal(0.0, 4.0, (n, 3))
+    boxes = np.concatenate([c - 0.2, c + 0.2], axis=1)
+    tokens, _ = gpu.bvh_build(boxes)
+    entries, offsets = object_entries(n)
+    want = []
+    where = np.zeros(len(tokens) + 1, dtype=np.int64)  # token -> position of its first entry
+    for k, t in enumerate(tokens):
+        where[k] = len(want)
+        if t["meta"] == abi.RT_BVH_TOKEN_LEAF:
+            o = int(t["link"])
+            for e in entries[offsets[o]:offsets[o + 1]]:
+                e = e.copy()
+                if (e["meta"] & 15) in (0, 8):
+                    e["link"] = int(e["link"]) - int(offsets[o]) + len(want) - (len(want) - where[k])
+                want.append(e)
+        else:
+            want.append(t.copy())
+    where[len(tokens)] = len(want)
+    want = np.array(want, dtype=abi.NODE_DTYPE)
+    inner = (want["meta"] & 15) == 0
+    want["link"][inner] = where[want["link"][inner]]
+    got = np.zeros(n - 1 + len(entries), dtype=abi.NODE_DTYPE)
+    gpu.check(gpu.lib.rt_bvh_build_stream(boxes.ctypes.data, n, entries.ctypes.data, offsets.ctypes.data, got.ctypes.data, None))
+    assert got.tobytes() == want.tobytes()
+    wrong = np.zeros(5, dtype=abi.NODE_DTYPE)
+    assert gpu.lib.rt_bvh_build_stream(boxes.ctypes.data, n, entries.ctypes.data, None, wrong.ctypes.data, None) == abi.RT_E_INVALID
+
+
+@pytest.mark.parametrize("n", [2, 65, 3000])
+def test_refit_gives_every_node_the_box_of_its_leaves(gpu, n):
+    import torch
+    rng = np.random.default_rng(n + 1)
+    c = rng.normal(0.0, 4.0, (n, 3))
+    h = rng.uniform(0.05, 0.3, (n, 3))
+    a = np.concatenate([c - h, c + h], axis=1)
+    tokens, _ = gpu.bvh_build(a)
+    moved = a.copy()
+    shift = rng.normal(0.0, 0.5, (n, 3))
+    moved[:, :3] += shift
+    moved[:, 3:] += shift
+    moved[::11, 4] = moved[::11, 1]  # some flat boxes
+
+    def refit(boxes):
+        d_tok = torch.from_numpy(tokens.view(np.uint8).copy()).cuda()
+        d_box = torch.from_numpy(boxes).cuda()
+        flag = torch.full((1,), 9, dtype=torch.int32, device="cuda")
+        gpu.check(gpu.lib.rt_bvh_refit_device(d_tok.data_ptr(), n, d_box.data_ptr(), flag.data_ptr(), None))
+        torch.cuda.synchronize()
+        return d_tok.cpu().numpy().view(abi.NODE_DTYPE), int(flag.item())
+
+    same, flag = refit(a)
+    assert same.tobytes() == tokens.tobytes() and flag == 0  # the boxes it was built over: nothing changes
+    got, flag = refit(moved)
+    assert flag == 0
+    assert np.array_equal(got["meta"], tokens["meta"]) and np.array_equal(got["link"], tokens["link"])
+    leaf = tokens["meta"] == abi.RT_BVH_TOKEN_LEAF
+    for p in np.nonzero(~leaf)[0]:
+        end = int(tokens["link"][p])
+        objs = tokens["link"][p + 1:end][leaf[p + 1:end]]
+        lo, hi = moved[objs, :3].min(axis=0), moved[objs, 3:].max(axis=0)
+        if (lo == hi).any():
+            assert np.isposinf(got["lo"][p]).all() and np.isneginf(got["hi"][p]).all()
+        else:
+            l, hh = f32_outward(lo, hi)
+            assert np.array_equal(got["lo"][p], l) and np.array_equal(got["hi"][p], hh), p
+    bad = moved.copy()
+    bad[0, 0] = np.nan
+    _, flag = refit(bad)
+    assert flag == 1
