@@ -61,6 +61,7 @@ struct Tls {
     uint64_t n_box = 0;              // BVHNode box tests
     uint64_t n_prim[K_NKINDS] = {};  // primitive hit() calls by kind
     uint64_t n_rays = 0;             // world.hit queries issued by ray_color
+    bool in_boundary = false;        // inside the boundary queries of a ConstantMedium
     std::vector<RayRecord>* recorder = nullptr;
     uint32_t record_max_bounce = 0;
 };
@@ -428,8 +429,40 @@ struct Hittable {  // :43-46
     virtual ~Hittable() = default;
     virtual bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const = 0;
     virtual bool bounding_box(double t0, double t1, AABB& output_box) const = 0;
+    // called when BVHNode::new makes this object a direct child of a node built over (t0, t1); see CullBox
+    virtual void adopted_by_bvh(double, double) const {}
+    virtual const Hittable& unwrap() const { return *this; }  // the object a chain of Translate / RotateY wraps
+    virtual bool one_entry() const { return false; }          // a single primitive
 };
 using HitPtr = std::shared_ptr<Hittable>;
+
+// Not in the reference: the product's flattener puts a box entry in front of every Translate / RotateY that is a
+// direct child of a BVHNode (the box the wrapper presented to BVHNode::new), so that rays which pass the node's box
+// but miss the wrapper's own are not moved into its space and back. Pure culling. The oracle does the same in its
+// two GPU box modes, counted as a box test, so that traversal work stays comparable; the reference mode does not.
+struct CullBox {
+    mutable FBox fbox;
+    mutable bool has = false;
+    void adopt(const Hittable& self, double t0, double t1) const {
+        AABB b;
+        has = !self.unwrap().one_entry() && self.bounding_box(t0, t1, b);  // not around a single primitive
+        if (!has) return;
+        // padded (2^-20 of the box's size and position) before it is rounded outward, so that no face of the object
+        // coincides with a face of the box: a hit on such a face at exactly the running closest t would otherwise be
+        // culled, where the reference accepts it
+        for (int a = 0; a < 3; ++a) {
+            const double scale = std::fmax(std::fmax(std::fabs(b._min[a]), std::fabs(b._max[a])), b._max[a] - b._min[a]);
+            const double pad = std::fmax(scale, 1e-30) * (1.0 / 1048576.0);
+            fbox.lo[a] = f32_down(b._min[a] - pad);
+            fbox.hi[a] = f32_up(b._max[a] + pad);
+        }
+    }
+    bool culls(const Ray& r, double t_min, double t_max) const {
+        if (!has || tls.aabb_mode == AABB_REFERENCE || tls.in_boundary) return false;
+        ++tls.n_box;
+        return !(tls.aabb_mode == AABB_TIGHT ? fbox.hit(r, t_min, t_max) : fbox.hit_per_axis(r, t_min, t_max));
+    }
+};
 
 inline void get_sphere_uv(const Vec3& p, double& u, double& v) {  // :64-69
     double phi = std::atan2(p.z, p.x);
@@ -439,6 +472,7 @@ inline void get_sphere_uv(const Vec3& p, double& u, double& v) {  // :64-69
 }
 
 struct Sphere : Hittable {  // :48-122
+    bool one_entry() const override { return true; }
     Point center;
     double radius;
     MatPtr mat_ptr;
@@ -507,6 +541,7 @@ struct HittableList : Hittable {  // :124-185
 };
 
 struct MovingSphere : Hittable {  // :187-260
+    bool one_entry() const override { return true; }
     Point center0, center1;
     double time0, time1, radius;
     MatPtr mat_ptr;
@@ -555,7 +590,11 @@ struct Translate : Hittable {  // :262-304
     Vec3 offset;
     uint32_t id;
     Translate(HitPtr p, const Vec3& displacement) : ptr(std::move(p)), offset(displacement), id(take_inst_id()) {}
+    CullBox cull;
+    const Hittable& unwrap() const override { return ptr->unwrap(); }
+    void adopted_by_bvh(double t0, double t1) const override { cull.adopt(*this, t0, t1); }
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :277-292
+        if (cull.culls(r, t_min, t_max)) return false;
         Ray moved_r{r.orig - offset, r.dire, r.tm};
         if (!ptr->hit(moved_r, t_min, t_max, rec)) return false;
         rec.p += offset;
@@ -600,7 +639,11 @@ struct RotateY : Hittable {  // :306-392
                 }
         bbox = AABB(min, max);
     }
+    CullBox cull;
+    const Hittable& unwrap() const override { return ptr->unwrap(); }
+    void adopted_by_bvh(double t0, double t1) const override { cull.adopt(*this, t0, t1); }
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :354-387
+        if (cull.culls(r, t_min, t_max)) return false;
         Vec3 orig = r.orig;
         Vec3 dire = r.dire;
         orig.x = cos_theta * r.orig[0] - sin_theta * r.orig[2];
@@ -630,6 +673,7 @@ struct RotateY : Hittable {  // :306-392
 // One struct for the three orientations: axis 0 = XYRect (:7-56, plane z = k),
 // 1 = XZRect (:58-107, plane y = k), 2 = YZRect (:109-158, plane x = k).
 struct AARect : Hittable {
+    bool one_entry() const override { return true; }
     int axis;
     double a0, a1, b0, b1, k;
     MatPtr mp;
@@ -676,6 +720,7 @@ inline HitPtr YZRect(double y0, double y1, double z0, double z1, double k, MatPt
 
 // --------------------------------------------------------------------- box6.rs
 struct Box6 : Hittable {  // :9-85; sides share the box's id and carry their index
+    bool one_entry() const override { return true; }
     Point box_min, box_max;
     HittableList sides;
     uint32_t id;
@@ -699,6 +744,7 @@ struct Box6 : Hittable {  // :9-85; sides share the box's id and carry their ind
 
 // ----------------------------------------------------------------- triangle.rs
 struct Triangle : Hittable {  // :7-84 (constructor argument order point1, point2, point0: :15)
+    bool one_entry() const override { return true; }
     Point point1, point2, point0;
     MatPtr mp;
     uint32_t id;
@@ -838,8 +884,12 @@ struct ConstantMedium : Hittable {  // :10-94
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :34-89
         ++tls.n_prim[K_MEDIUM];
         HitRecord rec1, rec2;
-        if (!boundary->hit(r, -INF, INF, rec1)) return false;
-        if (!boundary->hit(r, rec1.t + 0.0001, INF, rec2)) return false;
+        struct Inside { bool was; Inside() : was(tls.in_boundary) { tls.in_boundary = true; } ~Inside() { tls.in_boundary = was; } };
+        {
+            Inside scope;
+            if (!boundary->hit(r, -INF, INF, rec1)) return false;
+            if (!boundary->hit(r, rec1.t + 0.0001, INF, rec2)) return false;
+        }
         if (rec1.t < t_min) rec1.t = t_min;
         if (rec2.t > t_max) rec2.t = t_max;
         if (rec1.t > rec2.t) return false;
@@ -945,6 +995,10 @@ inline std::shared_ptr<BVHNode> new_from_list(std::vector<HitPtr>& objects, size
         throw std::runtime_error("no bounding box");  // :83-87
     temp->_box = surrounding_box(box_left, box_right);
     temp->fbox = FBox::from(temp->_box);
+    if (object_span <= 2) {  // its children are objects of the list, not nodes
+        temp->left->adopted_by_bvh(time0, time1);
+        if (temp->right.get() != temp->left.get()) temp->right->adopted_by_bvh(time0, time1);
+    }
     return temp;
 }
 
@@ -977,6 +1031,7 @@ inline std::shared_ptr<BVHNode> lbvh_from_list(const std::vector<HitPtr>& object
         if (!objects[i]->bounding_box(time0, time1, b)) throw std::runtime_error("no bounding box");
         for (int a = 0; a < 3; ++a) { boxes[6 * i + a] = b._min[a]; boxes[6 * i + 3 + a] = b._max[a]; }
     }
+    for (const HitPtr& o : objects) o->adopted_by_bvh(time0, time1);
     const std::vector<RtNode> tokens = orc_lbvh::build_tokens(boxes.data(), objects.size());
     size_t at = 0;
     HitPtr root = lbvh_subtree(tokens, at, objects, time0, time1);

@@ -35,16 +35,21 @@ def test_flatten_structure(rtlib, orc, sid):
     kinds = nodes["meta"] & 15
     idx = nodes["meta"] >> 4
     assert kinds[0] == K["inner"] and nodes["link"][0] == n  # the world is a BVHNode spanning the stream
-    # every inner node: 1 or 2 children exactly filling [i+1, link); its f32 box contains inner children's boxes
+    # every inner node: 1 or 2 children exactly filling [i+1, link); its f32 box contains inner children's boxes.
+    # A box entry directly in front of a wrapper is the culling box the flattener adds for a Translate / RotateY that is
+    # a leaf of a tree (not in the reference): one child, the wrapper, and padded slightly beyond the wrapper's own box.
     for i in np.nonzero(kinds == K["inner"])[0]:
         end = int(nodes["link"][i])
         assert i < end <= n
+        if kinds[i + 1] == K["xf_enter"] and walk_subtree_end(nodes, i + 1) == end:
+            continue
         c1 = walk_subtree_end(nodes, i + 1)
         assert c1 <= end
         if c1 < end:
             assert walk_subtree_end(nodes, c1) == end
         for c in (i + 1, c1):
-            if c < end and kinds[c] == K["inner"] and np.isfinite(nodes["lo"][c]).all() and np.isfinite(nodes["lo"][i]).all():
+            cull = c < end and kinds[c] == K["inner"] and c + 1 < n and kinds[c + 1] == K["xf_enter"]
+            if c < end and kinds[c] == K["inner"] and not cull and np.isfinite(nodes["lo"][c]).all() and np.isfinite(nodes["lo"][i]).all():
                 assert (nodes["lo"][i] <= nodes["lo"][c]).all() and (nodes["hi"][i] >= nodes["hi"][c]).all()
     # table indices in range, one table entry per distinct object, creation-order ids form a permutation
     ids = []
@@ -151,11 +156,33 @@ def test_builder_span_one_and_shared_objects(rtlib):
     hs = lib.HostScene(rtlib, b.finish(b.bvh(b.list(objs))))
     nodes = hs.table("nodes")
     kinds = (nodes["meta"] & 15).tolist()
-    # 3 objects: the BVH has a span-1 node (left == right, emitted once) and a span-2 node
+    # 3 objects: the BVH has a span-1 node (left == right, emitted once) and a span-2 node; a wrapper around a single
+    # primitive gets no culling box
     assert kinds.count(K["inner"]) == 3 and kinds.count(K["box6"]) == 2 and hs.desc.n_boxes == 1
     assert hs.desc.n_xforms == 2
     xf = hs.table("xforms")
     assert xf["kind"].tolist() == [0, 1] and xf["depth"].tolist() == [1, 2] and xf["inst_id"].tolist() == [1, 0]
+    hs.close()
+
+
+def test_culling_box_in_front_of_a_wrapped_tree(rtlib):
+    # Translate(RotateY(BVHNode)) as a leaf of the world tree (the sphere cluster of final_scene, src/main.rs:690-696):
+    # a box entry holding the wrapper's own bounding box, slightly padded, comes first and skips the whole wrapper
+    b = rtlib.host.builder()
+    m = b.lambertian([0.7, 0.7, 0.7])
+    cluster = b.bvh(b.list([b.sphere([float(i), 0.5 * i, 1.0], 0.4, m) for i in range(5)]))
+    wrapped = b.translate(b.rotate_y(cluster, 15.0), [-10.0, 2.0, 3.0])
+    hs = lib.HostScene(rtlib, b.finish(b.bvh(b.list([wrapped, b.sphere([30, 0, 0], 1.0, m)]))))
+    nodes = hs.table("nodes")
+    kinds = (nodes["meta"] & 15).tolist()
+    at = kinds.index(K["xf_enter"])
+    assert kinds[at - 1] == K["inner"] and kinds[at + 1] == K["xf_enter"]
+    end = int(nodes["link"][at - 1])
+    assert kinds[end - 1] == K["xf_exit"] and kinds[end - 2] == K["xf_exit"] and kinds[end] == K["sphere"]
+    root_lo, root_hi = nodes["lo"][0], nodes["hi"][0]
+    lo, hi = nodes["lo"][at - 1], nodes["hi"][at - 1]
+    assert (lo < hi).all() and (lo[0] < root_lo[0] or np.isclose(lo[0], root_lo[0], rtol=1e-5))  # the padded box may reach past the root's
+    assert hi[0] < 0 and lo[0] > -20  # around the translated cluster, not around the far sphere
     hs.close()
 
 
