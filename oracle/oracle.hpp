@@ -430,7 +430,9 @@ struct Hittable {  // :43-46
     virtual bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const = 0;
     virtual bool bounding_box(double t0, double t1, AABB& output_box) const = 0;
     // called when BVHNode::new makes this object a direct child of a node built over (t0, t1); see CullBox
-    virtual void adopted_by_bvh(double, double) const {}
+    // many_boxes: the list the tree was made from holds at least K_MANY_BOXES boxes of six sides
+    virtual void adopted_by_bvh(double, double, bool /*many_boxes*/) const {}
+    virtual bool is_box6() const { return false; }
     virtual const Hittable& unwrap() const { return *this; }  // the object a chain of Translate / RotateY wraps
     virtual bool one_entry() const { return false; }          // a single primitive
 };
@@ -443,9 +445,10 @@ using HitPtr = std::shared_ptr<Hittable>;
 struct CullBox {
     mutable FBox fbox;
     mutable bool has = false;
-    void adopt(const Hittable& self, double t0, double t1) const {
+    void adopt(const Hittable& self, double t0, double t1, bool primitive = false) const {
         AABB b;
-        has = !self.unwrap().one_entry() && self.bounding_box(t0, t1, b);  // not around a single primitive
+        // a wrapper: not around a single primitive; a primitive (a box of six sides that is a leaf of a tree): always
+        has = (primitive || !self.unwrap().one_entry()) && self.bounding_box(t0, t1, b);
         if (!has) return;
         // padded (2^-20 of the box's size and position) before it is rounded outward, so that no face of the object
         // coincides with a face of the box: a hit on such a face at exactly the running closest t would otherwise be
@@ -592,7 +595,7 @@ struct Translate : Hittable {  // :262-304
     Translate(HitPtr p, const Vec3& displacement) : ptr(std::move(p)), offset(displacement), id(take_inst_id()) {}
     CullBox cull;
     const Hittable& unwrap() const override { return ptr->unwrap(); }
-    void adopted_by_bvh(double t0, double t1) const override { cull.adopt(*this, t0, t1); }
+    void adopted_by_bvh(double t0, double t1, bool) const override { cull.adopt(*this, t0, t1); }
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :277-292
         if (cull.culls(r, t_min, t_max)) return false;
         Ray moved_r{r.orig - offset, r.dire, r.tm};
@@ -641,7 +644,7 @@ struct RotateY : Hittable {  // :306-392
     }
     CullBox cull;
     const Hittable& unwrap() const override { return ptr->unwrap(); }
-    void adopted_by_bvh(double t0, double t1) const override { cull.adopt(*this, t0, t1); }
+    void adopted_by_bvh(double t0, double t1, bool) const override { cull.adopt(*this, t0, t1); }
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :354-387
         if (cull.culls(r, t_min, t_max)) return false;
         Vec3 orig = r.orig;
@@ -732,7 +735,13 @@ struct Box6 : Hittable {  // :9-85; sides share the box's id and carry their ind
         sides.add(std::make_shared<AARect>(2, p0.y, p1.y, p0.z, p1.z, p1.x, ptr, id, 4));  // :56-63
         sides.add(std::make_shared<AARect>(2, p0.y, p1.y, p0.z, p1.z, p0.x, ptr, id, 5));  // :64-71
     }
+    CullBox cull;
+    bool is_box6() const override { return true; }
+    void adopted_by_bvh(double t0, double t1, bool many_boxes) const override {
+        if (many_boxes) cull.adopt(*this, t0, t1, true); else cull.has = false;
+    }
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :78-80
+        if (cull.culls(r, t_min, t_max)) return false;
         ++tls.n_prim[K_BOX6];
         return sides.hit(r, t_min, t_max, rec);
     }
@@ -941,6 +950,11 @@ struct BVHNode : Hittable {  // :10-15
     }
 };
 
+// Boxes of six sides that are leaves of a tree get a culling box of their own (CullBox) when the list the tree is made
+// from holds at least this many of them; the product's flattener applies the same rule.
+constexpr size_t K_MANY_BOXES = 8;
+inline thread_local bool bvh_many_boxes = false;
+
 inline bool box_less(const HitPtr& a, const HitPtr& b, int axis) {  // box_compare :119-134 (times 0,0)
     AABB box_a, box_b;
     if (!a->bounding_box(0.0, 0.0, box_a) || !b->bounding_box(0.0, 0.0, box_b)) throw std::runtime_error("no bounding box");
@@ -996,8 +1010,8 @@ inline std::shared_ptr<BVHNode> new_from_list(std::vector<HitPtr>& objects, size
     temp->_box = surrounding_box(box_left, box_right);
     temp->fbox = FBox::from(temp->_box);
     if (object_span <= 2) {  // its children are objects of the list, not nodes
-        temp->left->adopted_by_bvh(time0, time1);
-        if (temp->right.get() != temp->left.get()) temp->right->adopted_by_bvh(time0, time1);
+        temp->left->adopted_by_bvh(time0, time1, bvh_many_boxes);
+        if (temp->right.get() != temp->left.get()) temp->right->adopted_by_bvh(time0, time1, bvh_many_boxes);
     }
     return temp;
 }
@@ -1031,7 +1045,9 @@ inline std::shared_ptr<BVHNode> lbvh_from_list(const std::vector<HitPtr>& object
         if (!objects[i]->bounding_box(time0, time1, b)) throw std::runtime_error("no bounding box");
         for (int a = 0; a < 3; ++a) { boxes[6 * i + a] = b._min[a]; boxes[6 * i + 3 + a] = b._max[a]; }
     }
-    for (const HitPtr& o : objects) o->adopted_by_bvh(time0, time1);
+    size_t n_box6 = 0;
+    for (const HitPtr& o : objects) n_box6 += o->is_box6() ? 1 : 0;
+    for (const HitPtr& o : objects) o->adopted_by_bvh(time0, time1, n_box6 >= K_MANY_BOXES);
     const std::vector<RtNode> tokens = orc_lbvh::build_tokens(boxes.data(), objects.size());
     size_t at = 0;
     HitPtr root = lbvh_subtree(tokens, at, objects, time0, time1);
@@ -1040,6 +1056,15 @@ inline std::shared_ptr<BVHNode> lbvh_from_list(const std::vector<HitPtr>& object
 
 inline std::shared_ptr<BVHNode> BVHNode_new(HittableList& list, double time0, double time1) {  // :94-97
     if (list.objects.empty()) throw std::runtime_error("BVHNode::new on an empty list");
+    struct ManyBoxes {  // for the builders below, restored on the way out (trees nest: a list may hold a tree)
+        bool was;
+        explicit ManyBoxes(const std::vector<HitPtr>& objects) : was(bvh_many_boxes) {
+            size_t n = 0;
+            for (const HitPtr& o : objects) n += o->is_box6() ? 1 : 0;
+            bvh_many_boxes = n >= K_MANY_BOXES;
+        }
+        ~ManyBoxes() { bvh_many_boxes = was; }
+    } scope(list.objects);
     if (bvh_lbvh && list.objects.size() >= 2) {
         // the scene stream moves on as if the reference builder had drawn its axis per node (:24), so that whatever the
         // scene draws afterwards is the same under either tree policy

@@ -323,7 +323,9 @@ struct Hittable {
     virtual void flatten(Flat& f) const = 0;
     // Called when BVHNode::new makes this object a direct child of a node built over (t0, t1). Translate / RotateY
     // keep the box they presented then (see CullBox).
-    virtual void adopted_by_bvh(double, double) const {}
+    // many_boxes: the list the tree was made from holds at least kManyBoxes boxes of six sides
+    virtual void adopted_by_bvh(double, double, bool /*many_boxes*/) const {}
+    virtual bool is_box6() const { return false; }
     // the object a chain of Translate / RotateY wraps, and whether an object is one primitive (one stream entry)
     virtual const Hittable& unwrap() const { return *this; }
     virtual bool one_entry() const { return false; }
@@ -338,6 +340,44 @@ protected:
     uint32_t flat_store(const Flat& f, uint32_t idx) const { flat_gen_ = f.gen; flat_idx_ = idx; return idx; }
 };
 using HitPtr = std::shared_ptr<Hittable>;
+
+// The reference tests no box of its own before entering a Translate / RotateY that is a leaf of a BVH: a ray that
+// passes the parent node's box (the union with the sibling's) is moved into the wrapper's space and back even when
+// it misses the wrapper's own box. Entering and leaving a wrapper are the most expensive entries of the stream and
+// the least coherent ones, so the flattener puts a box entry in front of such a wrapper when it holds more than one
+// primitive: the box the wrapper presented to BVHNode::new. Pure culling: the closest hit is the same.
+inline bool cull_boxes_enabled() {
+    static const bool off = std::getenv("RT_NO_CULL_BOXES") != nullptr;  // developer knob for A/B measurements
+    return !off;
+}
+inline double cull_pad(double mn, double mx) {
+    const double scale = std::fmax(std::fmax(std::fabs(mn), std::fabs(mx)), mx - mn);
+    return std::fmax(scale, 1e-30) * (1.0 / 1048576.0);
+}
+struct CullBox {
+    mutable AABB box;
+    mutable bool has = false;
+    // Not around a single primitive: that is tested in one step inside its wrappers, without entering and leaving
+    // them, and a box in front of it only adds a step (measured on the Cornell box: 15 % slower with one).
+    void adopt(const Hittable& self, double t0, double t1) const { has = !self.unwrap().one_entry() && self.bounding_box(t0, t1, box); }
+    void adopt_primitive(const Hittable& self, double t0, double t1) const { has = self.bounding_box(t0, t1, box); }
+    // the box entry in front of the wrapper's entries; returns its position or NONE
+    uint32_t open(Flat& f) const {
+        if (!has || f.in_medium || !cull_boxes_enabled()) return 0xFFFFFFFFu;
+        const uint32_t at = f.push_node(RT_N_INNER, 0);
+        // Padded before it is rounded outward: no face of the object may coincide with a face of this box, or a hit
+        // on that face at exactly the running closest t (two objects hit at the same t, where the reference lets the
+        // later one win) would be culled by the test's `far <= near`. The pad is relative to the box (2^-20 of its
+        // size and position), far above rounding noise and far below anything a picture shows.
+        for (int a = 0; a < 3; ++a) {
+            const double pad = cull_pad(box._min[a], box._max[a]);
+            f.nodes[at].lo[a] = f32_down(box._min[a] - pad);
+            f.nodes[at].hi[a] = f32_up(box._max[a] + pad);
+        }
+        return at;
+    }
+    static void close(Flat& f, uint32_t at) { if (at != 0xFFFFFFFFu) f.nodes[at].link = (uint32_t)f.nodes.size(); }
+};
 
 struct Sphere : Hittable {  // src/hittable.rs:48-62, 115-121
     bool one_entry() const override { return true; }
@@ -432,7 +472,13 @@ struct Box6 : Hittable {  // src/box6.rs:9-85; the six rects of :22-71 are impli
     uint32_t id;
     Box6(Point p0, Point p1, MatPtr m) : box_min(p0), box_max(p1), mat(std::move(m)), id(ctx().next_prim++) {}
     bool bounding_box(double, double, AABB& out) const override { out._min = box_min; out._max = box_max; return true; }
+    CullBox cull;
+    bool is_box6() const override { return true; }
+    void adopted_by_bvh(double t0, double t1, bool many_boxes) const override {
+        if (many_boxes) cull.adopt_primitive(*this, t0, t1); else cull.has = false;
+    }
     void flatten(Flat& f) const override {
+        const uint32_t cull_at = cull.open(f);
         uint32_t idx;
         if (!flat_lookup(f, idx)) {
             RtBox6 b{};
@@ -441,6 +487,7 @@ struct Box6 : Hittable {  // src/box6.rs:9-85; the six rects of :22-71 are impli
             idx = flat_store(f, (uint32_t)f.boxes.size() - 1);
         }
         f.push_node(RT_N_BOX6, idx);
+        CullBox::close(f, cull_at);
     }
 };
 
@@ -508,43 +555,6 @@ inline void push_xform(Flat& f, const RtXform& proto, const Hittable& child) {
     f.push_node(RT_N_XF_EXIT, self);
 }
 
-// The reference tests no box of its own before entering a Translate / RotateY that is a leaf of a BVH: a ray that
-// passes the parent node's box (the union with the sibling's) is moved into the wrapper's space and back even when
-// it misses the wrapper's own box. Entering and leaving a wrapper are the most expensive entries of the stream and
-// the least coherent ones, so the flattener puts a box entry in front of such a wrapper when it holds more than one
-// primitive: the box the wrapper presented to BVHNode::new. Pure culling: the closest hit is the same.
-inline bool cull_boxes_enabled() {
-    static const bool off = std::getenv("RT_NO_CULL_BOXES") != nullptr;  // developer knob for A/B measurements
-    return !off;
-}
-inline double cull_pad(double mn, double mx) {
-    const double scale = std::fmax(std::fmax(std::fabs(mn), std::fabs(mx)), mx - mn);
-    return std::fmax(scale, 1e-30) * (1.0 / 1048576.0);
-}
-struct CullBox {
-    mutable AABB box;
-    mutable bool has = false;
-    // Not around a single primitive: that is tested in one step inside its wrappers, without entering and leaving
-    // them, and a box in front of it only adds a step (measured on the Cornell box: 15 % slower with one).
-    void adopt(const Hittable& self, double t0, double t1) const { has = !self.unwrap().one_entry() && self.bounding_box(t0, t1, box); }
-    // the box entry in front of the wrapper's entries; returns its position or NONE
-    uint32_t open(Flat& f) const {
-        if (!has || f.in_medium || !cull_boxes_enabled()) return 0xFFFFFFFFu;
-        const uint32_t at = f.push_node(RT_N_INNER, 0);
-        // Padded before it is rounded outward: no face of the object may coincide with a face of this box, or a hit
-        // on that face at exactly the running closest t (two objects hit at the same t, where the reference lets the
-        // later one win) would be culled by the test's `far <= near`. The pad is relative to the box (2^-20 of its
-        // size and position), far above rounding noise and far below anything a picture shows.
-        for (int a = 0; a < 3; ++a) {
-            const double pad = cull_pad(box._min[a], box._max[a]);
-            f.nodes[at].lo[a] = f32_down(box._min[a] - pad);
-            f.nodes[at].hi[a] = f32_up(box._max[a] + pad);
-        }
-        return at;
-    }
-    static void close(Flat& f, uint32_t at) { if (at != 0xFFFFFFFFu) f.nodes[at].link = (uint32_t)f.nodes.size(); }
-};
-
 struct Translate : Hittable {  // src/hittable.rs:262-304
     HitPtr ptr;
     Vec3 offset;
@@ -558,7 +568,7 @@ struct Translate : Hittable {  // src/hittable.rs:262-304
     }
     CullBox cull;
     const Hittable& unwrap() const override { return ptr->unwrap(); }
-    void adopted_by_bvh(double t0, double t1) const override { cull.adopt(*this, t0, t1); }
+    void adopted_by_bvh(double t0, double t1, bool) const override { cull.adopt(*this, t0, t1); }
     void flatten(Flat& f) const override {
         RtXform x{};
         x.kind = 0; x.inst_id = id; put3(x.offset, offset);
@@ -600,7 +610,7 @@ struct RotateY : Hittable {  // src/hittable.rs:306-392
     bool bounding_box(double, double, AABB& out) const override { out = bbox; return hasbox; }
     CullBox cull;
     const Hittable& unwrap() const override { return ptr->unwrap(); }
-    void adopted_by_bvh(double t0, double t1) const override { cull.adopt(*this, t0, t1); }
+    void adopted_by_bvh(double t0, double t1, bool) const override { cull.adopt(*this, t0, t1); }
     void flatten(Flat& f) const override {
         RtXform x{};
         x.kind = 1; x.inst_id = id; x.sin_theta = sin_theta; x.cos_theta = cos_theta;
@@ -716,11 +726,22 @@ inline void rng_seek(rt::Rng& r, uint64_t draw) {
     }
 }
 
+// Boxes of six sides that are leaves of a tree get a culling box of their own (see CullBox) when the tree's list holds
+// at least this many of them (the 400 ground boxes of final_scene, src/main.rs:591-612): a lone box among other
+// objects is mostly hit by the rays that reach it, and the extra entry then only costs (10 M-triangle mesh: -9 %).
+constexpr size_t kManyBoxes = 8;
+inline bool many_boxes_in(const std::vector<HitPtr>& objects) {
+    size_t n = 0;
+    for (const HitPtr& o : objects) if (o->is_box6() && ++n >= kManyBoxes) return true;
+    return false;
+}
+
 struct BvhBuild {
     std::vector<HitPtr>& objects;
     double time0, time1;
     rt::Rng base;                                  // the scene stream (position irrelevant)
     bool widest;
+    bool many_boxes = false;
     std::unordered_map<size_t, uint64_t> draws;    // nodes (= draws) of a subtree over n objects
 
     uint64_t count_draws(size_t n) {
@@ -777,8 +798,8 @@ struct BvhBuild {
         node->_box = surrounding_box(bl, br);
         node->set_times(time0, time1);
         if (span <= 2) {  // its children are objects of the list, not nodes
-            node->left->adopted_by_bvh(time0, time1);
-            if (node->right.get() != node->left.get()) node->right->adopted_by_bvh(time0, time1);
+            node->left->adopted_by_bvh(time0, time1, many_boxes);
+            if (node->right.get() != node->left.get()) node->right->adopted_by_bvh(time0, time1, many_boxes);
         }
         return node;
     }
@@ -814,7 +835,8 @@ struct DeviceBvh : BVHNode {  // left / right stay empty: the tree is made on th
         if (objects.size() > RT_BVH_MAX_OBJECTS) throw std::invalid_argument("too many objects for one tree");
         std::vector<double> boxes;
         boxes_of(boxes, &_box);
-        for (const HitPtr& o : objects) o->adopted_by_bvh(time0, time1);
+        const bool many_boxes = many_boxes_in(objects);
+        for (const HitPtr& o : objects) o->adopted_by_bvh(time0, time1, many_boxes);
         // what rt_bvh_build refuses is refused here, where the reference's BVHNode::new would run (src/bvh.rs:94)
         for (size_t i = 0; i < objects.size(); ++i)
             for (int a = 0; a < 3; ++a) {
@@ -868,11 +890,11 @@ inline std::shared_ptr<BVHNode> BVHNode::create(HittableList& list, double time0
     if (g_bvh_device && list.objects.size() >= 2) {
         // the scene stream moves on as if the host recursion had drawn its axis per node, so that whatever the scene
         // draws afterwards is the same under either tree policy
-        BvhBuild counter{list.objects, time0, time1, ctx().rng, false, {}};
+        BvhBuild counter{list.objects, time0, time1, ctx().rng, false, false, {}};
         rng_seek(ctx().rng, rng_position(ctx().rng) + counter.count_draws(list.objects.size()));
         return std::make_shared<DeviceBvh>(list.objects, time0, time1);
     }
-    BvhBuild b{list.objects, time0, time1, ctx().rng, g_bvh_widest_axis, {}};
+    BvhBuild b{list.objects, time0, time1, ctx().rng, g_bvh_widest_axis, many_boxes_in(list.objects), {}};
     const uint64_t first = rng_position(ctx().rng);
     const uint64_t total = b.count_draws(list.objects.size());
     int fork_levels = 4;  // up to 16 subtrees at a time; RT_BVH_FORK_LEVELS=0 builds on the calling thread alone

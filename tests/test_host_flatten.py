@@ -37,18 +37,22 @@ def test_flatten_structure(rtlib, orc, sid):
     assert kinds[0] == K["inner"] and nodes["link"][0] == n  # the world is a BVHNode spanning the stream
     # every inner node: 1 or 2 children exactly filling [i+1, link); its f32 box contains inner children's boxes.
     # A box entry directly in front of a wrapper is the culling box the flattener adds for a Translate / RotateY that is
-    # a leaf of a tree (not in the reference): one child, the wrapper, and padded slightly beyond the wrapper's own box.
+    # a leaf of a tree, or for a box of six sides that is one (not in the reference): one child, padded slightly beyond
+    # the child's own box.
+    def is_cull(i):  # a box entry with exactly one child that is a wrapper or a box of six sides
+        return kinds[i + 1] in (K["xf_enter"], K["box6"]) and walk_subtree_end(nodes, i + 1) == int(nodes["link"][i])
+
     for i in np.nonzero(kinds == K["inner"])[0]:
         end = int(nodes["link"][i])
         assert i < end <= n
-        if kinds[i + 1] == K["xf_enter"] and walk_subtree_end(nodes, i + 1) == end:
+        if is_cull(i):
             continue
         c1 = walk_subtree_end(nodes, i + 1)
         assert c1 <= end
         if c1 < end:
             assert walk_subtree_end(nodes, c1) == end
         for c in (i + 1, c1):
-            cull = c < end and kinds[c] == K["inner"] and c + 1 < n and kinds[c + 1] == K["xf_enter"]
+            cull = c < end and kinds[c] == K["inner"] and is_cull(c)
             if c < end and kinds[c] == K["inner"] and not cull and np.isfinite(nodes["lo"][c]).all() and np.isfinite(nodes["lo"][i]).all():
                 assert (nodes["lo"][i] <= nodes["lo"][c]).all() and (nodes["hi"][i] >= nodes["hi"][c]).all()
     # table indices in range, one table entry per distinct object, creation-order ids form a permutation
