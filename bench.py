@@ -76,11 +76,19 @@ def scene_kwargs(wl, bvh="reference"):
         kw["n_triangles"] = wl["n_triangles"]
     if wl.get("boxes_per_side"):
         kw["boxes_per_side"] = wl["boxes_per_side"]
+    if wl.get("shutter_bvh"):
+        kw["flags"] = kw.get("flags", 0) | abi.RT_SCENE_BVH_SHUTTER_TIMES
     return kw
 
 
-def profile_key(workload, bvh):
-    return workload if bvh == "reference" else "%s_%s" % (workload, bvh)
+def profile_key(workload, bvh, wl=None):
+    """Key of a committed counter measurement: workload, tree policy and whatever else changes the scene."""
+    key = workload if bvh == "reference" else "%s_%s" % (workload, bvh)
+    if wl and wl.get("boxes_per_side"):
+        key += "_boxes%d" % wl["boxes_per_side"]
+    if wl and wl.get("shutter_bvh"):
+        key += "_shutter"
+    return key
 
 
 def measured_traffic(workload, spp):
@@ -141,13 +149,13 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(wl, spp, threads, more_threads=0):
+def cpu_baseline(wl, spp, threads, more_threads=0, bvh="reference"):
     """The CPU oracle (oracle/, a C++ restatement of the reference) on the same scene and image size, `spp`
     samples per pixel, `threads` std::threads splitting columns as src/main.rs:193-195 does; when `more_threads`
     is given, a second run with that many threads (the share of the host's cores this job may use) is reported too."""
     import oracle
     o = oracle.get()
-    kw = scene_kwargs(wl)
+    kw = scene_kwargs(wl, bvh)  # the same tree policy as the GPU run (the oracle builds the linear tree on the CPU)
     sc = o.api.scene_build(wl["scene"], **kw)
     su = o.api.scene_setup(wl["scene"])
     su.aspect_ratio = wl["width"] / wl["height"]
@@ -178,6 +186,9 @@ def main():
                          "or replaced by the linear BVH built on the GPU (rt_bvh_build)")
     ap.add_argument("--boxes-per-side", type=int, default=0,
                     help="final scene only: side of the ground grid of boxes (src/main.rs:591 has 20); larger grids no longer fit LDS")
+    ap.add_argument("--shutter-bvh", action="store_true",
+                    help="weekend only: build the tree over the shutter interval (0, 1) instead of the reference's (0, 0.1) (src/main.rs:315); boxes then "
+                         "bound the moving spheres and the kernels run the carried-interval box rule instead of the reference's per-axis one")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every GPU renders --spp-per-step samples per step; strong: a step is a fixed job of --spp samples of every pixel split over the GPUs")
     ap.add_argument("--spp", type=int, default=10000, help="--scaling strong: samples of every pixel in the whole job (BASELINE configs[3]: 10000)")
@@ -216,6 +227,9 @@ def main():
     if args.boxes_per_side and args.workload == "final":
         wl["boxes_per_side"] = args.boxes_per_side
         wl["name"] += " with %d x %d ground boxes" % (args.boxes_per_side, args.boxes_per_side)
+    if args.shutter_bvh and args.workload == "weekend":
+        wl["shutter_bvh"] = True
+        wl["name"] += ", tree built over the shutter interval"
     L = lib.get()
     t_build = time.time()
     hs = lib.HostScene.build(wl["scene"], **scene_kwargs(wl, args.bvh))
@@ -306,13 +320,13 @@ def main():
         secs_extend = ms_extend * 1e-3
         gbs = rays * bytes_per_ray / secs_extend / 1e9 if ms_extend > 0 else 0.0
         tflops = rays * flops_per_ray / secs_extend / 1e12 if ms_extend > 0 else 0.0
-        traffic = measured_traffic(profile_key(args.workload, args.bvh), S)
+        traffic = measured_traffic(profile_key(args.workload, args.bvh, wl), S)
         byte_side = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": rays * bytes_per_ray / launches, "bytes_per_ray": bytes_per_ray,
                      "measured_hbm_bytes_per_launch": traffic,
                      "measured_hbm_frac": (traffic / (secs_extend / launches) / 1e9 / HBM_PEAK_GBS) if traffic and ms_extend > 0 else None}
         flop_side = {"achieved": tflops, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_PEAK_TFLOPS,
-                     "algorithmic_flops_per_ray": flops_per_ray, "measured": measured_valu(profile_key(args.workload, args.bvh))}
+                     "algorithmic_flops_per_ray": flops_per_ray, "measured": measured_valu(profile_key(args.workload, args.bvh, wl))}
         # What binds: with the scene tables staged in LDS the entry and primitive bytes never leave the CU (HBM carries
         # only ray records and hit slots), and the kernel is bound by f64 vector issue at low lane utilisation; the byte
         # formula is then reported beside it, not as the bound. A scene whose tables stay in global memory is HBM /
@@ -339,7 +353,7 @@ def main():
             "roofline": roofline,
         }
         if args.cpu_spp > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_spp, args.cpu_threads, args.cpu_more_threads)
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_spp, args.cpu_threads, args.cpu_more_threads, args.bvh)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -7,6 +7,12 @@ for w in weekend cornell smoke; do
   timeout -k 10 200 python bench.py --workload $w --steps 3 --warmup 1 --cpu-spp 0 > gpurun_out/w_$w.json 2> gpurun_out/w_$w.err || exit 1
   echo "$w done"
 done
+timeout -k 10 200 python bench.py --workload weekend --shutter-bvh --steps 3 --warmup 1 --cpu-spp 0 > gpurun_out/w_weekend_shutter.json 2> gpurun_out/w_weekend_shutter.err || exit 1
+echo "weekend shutter done"
+for b in 40 60 100; do
+  timeout -k 10 200 python bench.py --boxes-per-side $b --steps 2 --warmup 1 --cpu-spp 0 > gpurun_out/w_final_$b.json 2> gpurun_out/w_final_$b.err || exit 1
+done
+echo "final with larger grids done"
 timeout -k 10 250 python bench.py --workload mesh --bvh lbvh --steps 2 --warmup 1 --cpu-spp 0 > gpurun_out/w_mesh_lbvh.json 2> gpurun_out/w_mesh_lbvh.err || exit 1
 echo "mesh lbvh done"
 timeout -k 10 280 python bench.py --workload mesh --bvh widest --steps 2 --warmup 1 --cpu-spp 0 > gpurun_out/w_mesh_widest.json 2> gpurun_out/w_mesh_widest.err || exit 1
