@@ -270,6 +270,55 @@ RT_D bool box6_hit(PB b, V3 o, V3 d, double tmin, double& tmax, uint32_t& side_o
     return any;
 }
 
+// The same answer as box6_hit for one division instead of six, for the rays whose case is clear-cut; every other ray
+// takes box6_hit. The list of six sides returns the accepted side with the smallest t (an equal t goes to the later
+// side), and a side is accepted when its t = (k - o) / d lies in [tmin, tmax] and the point at t lies within the side's
+// bounds. With the plane distances estimated as (k - o) * (1 / d) (within two ulp of the quotient) and a margin m far
+// above every rounding error involved:
+//   entry: the ray reaches the last of its three near planes at te > tmin + m, more than m after the other two and
+//          more than m before the first far plane. At that plane the ray is strictly inside the other two slabs (its
+//          side is in bounds), at the other two near planes it has not yet entered this slab (those sides are out of
+//          bounds), and the far sides lie beyond. The answer is that side, if its exact t is not above tmax.
+//   exit:  all three near planes lie more than m before tmin (those sides fail the range check) and the first far
+//          plane is reached at tx > tmin + m, more than m before the other two: that far side is in bounds and the
+//          other two lie beyond. The answer is that side, if its exact t is not above tmax.
+//   behind: the first far plane lies more than 2 m before tmin (a ray leaving the box it starts on): a side whose t
+//          is not below tmin is reached more than m after the ray has left that slab, out of bounds. No side is hit.
+// The margin is relative to the coordinates involved, not to t: a point o + t d is compared with bounds whose
+// rounding error scales with |o| and the plane positions.
+template <class PB>
+RT_D bool box6_hit_seg(PB b, const Seg& g, double tmin, double& tmax, uint32_t& side_out) {
+    const V3 p0 = v3p(b->p0), p1 = v3p(b->p1);
+    const double ex0 = p0.x - g.o.x, ex1 = p1.x - g.o.x, ey0 = p0.y - g.o.y, ey1 = p1.y - g.o.y, ez0 = p0.z - g.o.z, ez1 = p1.z - g.o.z;
+    const double x0 = ex0 * g.invd.x, x1 = ex1 * g.invd.x, y0 = ey0 * g.invd.y, y1 = ey1 * g.invd.y, z0 = ez0 * g.invd.z, z1 = ez1 * g.invd.z;
+    const double nx = fmin(x0, x1), fx = fmax(x0, x1), ny = fmin(y0, y1), fy = fmax(y0, y1), nz = fmin(z0, z1), fz = fmax(z0, z1);
+    const double te = fmax(fmax(nx, ny), nz), tx = fmin(fmin(fx, fy), fz);
+    const double te2 = fmax(fmin(nx, ny), fmin(fmax(nx, ny), nz));  // second largest near distance
+    const double tx2 = fmin(fmax(fx, fy), fmax(fmin(fx, fy), fz));  // second smallest far distance
+    const double scale = (fabs(g.o.x) + fabs(p0.x) + fabs(p1.x)) * fabs(g.invd.x) + (fabs(g.o.y) + fabs(p0.y) + fabs(p1.y)) * fabs(g.invd.y) +
+                         (fabs(g.o.z) + fabs(p0.z) + fabs(p1.z)) * fabs(g.invd.z);
+    const double m = scale * 0x1p-40;
+    // finite everywhere (no direction component is zero, nothing is NaN) and a box with volume
+    const bool regular = scale < 1e300 && p0.x < p1.x && p0.y < p1.y && p0.z < p1.z;
+    const bool entry = regular && te > tmin + m && te - te2 > m && tx - te > m;
+    const bool leave = regular && te < tmin - m && tx > tmin + m && tx2 - tx > m;
+    if (regular && tx < tmin - (m + m)) return false;
+    if (!(entry || leave)) return box6_hit(b, g.o, g.d, tmin, tmax, side_out);
+    const double ref = entry ? te : tx;  // exactly one of the six estimates equals it
+    double num = ez1, den = g.d.z;
+    uint32_t side = 0u;
+    if (z0 == ref) { num = ez0; side = 1u; }
+    if (y1 == ref) { num = ey1; den = g.d.y; side = 2u; }
+    if (y0 == ref) { num = ey0; den = g.d.y; side = 3u; }
+    if (x1 == ref) { num = ex1; den = g.d.x; side = 4u; }
+    if (x0 == ref) { num = ex0; den = g.d.x; side = 5u; }
+    const double t = num / den;  // the reference's (k - o) / d of that side
+    if (t < tmin || t > tmax) return false;
+    tmax = t;
+    side_out = side;
+    return true;
+}
+
 // Triangle::hit src/triangle.rs:26-59 (Moeller-Trumbore, two-sided, t range inclusive).
 template <class PT>
 RT_D bool triangle_hit(PT tr, V3 o, V3 d, double tmin, double tmax, double& t_out) {
@@ -474,7 +523,7 @@ struct Walker {
                 RT_DIAG_LEAF(RT_N_BOX6)
                 uint32_t side = 0u;
                 double t = best.t;
-                if (box6_hit(S.boxes + idx, g.o, g.d, tmin, t, side)) { best.t = t; best.ref = meta; best.aux = side | (cur_xf << 8); }
+                if (box6_hit_seg(S.boxes + idx, g, tmin, t, side)) { best.t = t; best.ref = meta; best.aux = side | (cur_xf << 8); }
                 break;
             }
             case RT_N_TRIANGLE: {
