@@ -8,6 +8,8 @@
 //   rec_gather96  lane i reads the six pieces of record perm[i]       (perm shuffles records within 6144-record windows:
 //                                                                      what the sorting shade kernel reads)
 //   hit_gather16  lane i reads 16 B at 16 * perm[i]                   (the hit slots behind the same permutation)
+//   node_gather32 lane i reads the 32 bytes at 32 * hash(i) of a 1.5 GB table, both halves requested together
+//                                                                     (entry fetches of a tree that lives in HBM)
 //   rec_write96   64 lanes write 64 records in address order, 16 B per lane per store (shade's survivor store)
 //
 // Build: hipcc -O3 --offload-arch=gfx950 -o tools/bin/fetch_calibrate tools/fetch_calibrate.hip
@@ -62,6 +64,18 @@ __global__ void hit_gather16(const uint4* __restrict__ in, const uint16_t* __res
             const uint4 v = in[base + perm[base + j]];
             acc ^= v.x ^ v.y ^ v.z ^ v.w;
         }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+__global__ void node_gather32(const uint4* __restrict__ in, uint32_t n_nodes, uint32_t n_reads, uint32_t* __restrict__ out) {
+    uint32_t acc = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += gridDim.x * blockDim.x) {
+        uint32_t h = i * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const uint4* r = in + (uint64_t)(h % n_nodes) * 2u;
+        const uint4 a = r[0], b = r[1];
+        acc ^= a.x ^ a.w ^ b.x ^ b.w;
     }
     if (acc == 0x12345678u) out[0] = acc;
 }
@@ -121,6 +135,8 @@ int main() {
         timed("rec_seq64", (double)n_rec * 64.0, [&] { rec_seq<4><<<grid, block>>>(recs, n_rec, out); });
         timed("rec_gather96", (double)bytes + 2.0 * n_rec, [&] { rec_gather96<<<dim3(256), block>>>(recs, perm, n_rec, out); });
         timed("hit_gather16", 18.0 * n_rec, [&] { hit_gather16<<<dim3(256), block>>>(hits, perm, n_rec, out); });
+        // 1.5 GB of 32-byte nodes, 64 M reads of 32 bytes = 2.0 GB asked for (repeats are rare: 64 M draws of 47 M nodes)
+        timed("node_gather32", 32.0 * (1u << 26), [&] { node_gather32<<<grid, block>>>(recs, (uint32_t)(bytes / 64u), 1u << 26, out); });
         timed("rec_write96", (double)bytes, [&] { rec_write96<<<grid, block>>>(recs, n_rec); });
     }
     CHECK(hipDeviceSynchronize());

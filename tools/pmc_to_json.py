@@ -2,10 +2,14 @@
 its roofline object: profiles/hbm_traffic.json (HBM bytes per closest-hit launch) and profiles/valu_issue.json (vector
 issue and lane utilisation of the same kernel).
 
-    python tools/pmc_to_json.py KEY TAG KERNEL SPP SECONDS_PER_LAUNCH
+    python tools/pmc_to_json.py KEY TAG KERNEL SPP SECONDS_PER_LAUNCH [RAYS_PER_LAUNCH]
 KEY: workload name as bench.py knows it, with the tree policy appended when not the reference's ("mesh_lbvh");
 TAG: the tag the summaries were written under (profiles/TAG_pmc_fetch.txt ...); KERNEL: e.g. "rtd::k_extend<false, true, 4>";
-SPP: samples per step of the profiled run; SECONDS_PER_LAUNCH: the kernel's average duration from the kernel trace."""
+SPP: samples per step of the profiled run; SECONDS_PER_LAUNCH: the kernel's average duration from the kernel trace;
+RAYS_PER_LAUNCH: give it for a scene whose tables live in HBM. FETCH_SIZE tallies the wide in-order reads of the ray
+records at half their bytes and scattered 32-byte entry reads at the 64 bytes they fetch (tools/fetch_calibrate.hip), so
+for a scene in LDS (reads = records only) FETCH_SIZE is doubled, and for a scene in HBM only the records' missing half,
+48 bytes per ray, is added."""
 import json
 import os
 import sys
@@ -29,7 +33,7 @@ def counters(path, kernel):
     return out
 
 
-def main(key, tag, kernel, spp, secs):
+def main(key, tag, kernel, spp, secs, rays_per_launch=None):
     prof = os.path.join(ROOT, "profiles")
     f = counters(os.path.join(prof, tag + "_pmc_fetch.txt"), kernel)
     w = counters(os.path.join(prof, tag + "_pmc_write.txt"), kernel)
@@ -39,10 +43,17 @@ def main(key, tag, kernel, spp, secs):
     doubled = (2.0 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024.0 / n
     path = os.path.join(prof, "hbm_traffic.json")
     t = json.load(open(path)) if os.path.exists(path) else {}
+    if rays_per_launch is None:
+        corrected = doubled
+        how = ("FETCH_SIZE doubled (gfx950 tallies 128-byte read requests at 64 bytes; this kernel's HBM reads are the in-order ray "
+               "records, the calibrated case); WRITE_SIZE as reported")
+    else:
+        corrected = raw + 48.0 * float(rays_per_launch)
+        how = ("FETCH_SIZE as reported (scattered 32-byte entry reads are tallied at the 64 bytes they fetch, tools/fetch_calibrate.hip) "
+               "plus 48 bytes per ray for the in-order ray records, which are tallied at half; WRITE_SIZE as reported")
     t[key] = {"kernel": kernel, "launches": n, "fetch_size_kib": f["FETCH_SIZE"], "write_size_kib": w["WRITE_SIZE"],
-              "bytes_per_launch": doubled, "bytes_per_launch_uncorrected": raw,
-              "correction": "FETCH_SIZE doubled (gfx950 tallies 128-byte read requests at 64 bytes; exact for wide coalesced reads, "
-                            "an upper bound for scattered 32-byte entry reads); WRITE_SIZE as reported",
+              "bytes_per_launch": corrected, "bytes_per_launch_uncorrected": raw,
+              "correction": how,
               "source": "profiles/%s_pmc_fetch.txt and profiles/%s_pmc_write.txt (rocprofv3 --pmc, separate passes)" % (tag, tag),
               "spp_per_step": int(spp)}
     json.dump(t, open(path, "w"), indent=1)
@@ -62,4 +73,4 @@ def main(key, tag, kernel, spp, secs):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:7])
