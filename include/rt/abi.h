@@ -262,7 +262,9 @@ int rt_path_step(RtScene* scene, const RtRenderParams* params, int profile, cons
 int rt_scene_profile(const RtScene* scene);
 
 /* Replaces the gamma / clamp / u8 conversion (src/main.rs:212-225): out =
- * clamp(sqrt(accum / spp), 0, 0.999) * 255 as u8. Host buffers / device buffers. */
+ * clamp(sqrt(accum / spp), 0, 0.999) * 255 as u8. Host buffers / device buffers. The host-buffer form is called once
+ * per picture and has no scene to keep staging memory in: it allocates and frees its two device buffers per call; the
+ * device form allocates nothing and is asynchronous on `stream`. */
 int rt_resolve_u8(const float* accum_rgb, uint32_t width, uint32_t height, uint64_t spp, uint8_t* rgb_out);
 int rt_resolve_u8_device(const float* accum_rgb_dev, uint32_t width, uint32_t height, uint64_t spp, uint8_t* rgb_out_dev,
                          void* stream);
