@@ -52,7 +52,12 @@ enum RtError {
  * and HittableList::hit (src/hittable.rs:151-164) do.
  *   meta = kind | index << 4
  *   RT_N_INNER   : lo/hi = box of a BVHNode (src/bvh.rs:14), link = entry to
- *                  continue at when the box is missed (one past its subtree)
+ *                  continue at when the box is missed (one past its subtree);
+ *                  index = 0, or RT_INNER_CARRIED (1): the box is known to hold
+ *                  everything in its subtree for every ray time. Only looked at
+ *                  in a scene flagged RT_DESC_BOXES_MAY_NOT_BOUND, where such a
+ *                  box is tested with the carried interval like the boxes of any
+ *                  other scene, and the others with the reference's per-axis rule
  *   RT_N_SPHERE .. RT_N_TRIANGLE : index into the matching primitive table
  *   RT_N_XF_ENTER: index into xforms; the ray is moved into the wrapper's
  *                  object space (src/hittable.rs:278-282, 355-368)
@@ -66,6 +71,8 @@ typedef struct RtNode {
     uint32_t meta;
     uint32_t link;
 } RtNode;
+
+#define RT_INNER_CARRIED 1u
 
 enum RtNodeKind {
     RT_N_INNER = 0, RT_N_SPHERE = 1, RT_N_MSPHERE = 2, RT_N_RECT = 3, RT_N_BOX6 = 4,
@@ -121,7 +128,10 @@ typedef struct RtImage {         /* src/texture.rs:75-79; texels are RGB u8 rows
  * random_scene builds its tree over t in (0, 0.1) while its spheres move over (0, 1): src/main.rs:315, 267-279).
  * The closest hit then depends on the box rule, and the kernels run the reference's own per-axis rule
  * (src/aabb.rs:15-30) on such a scene instead of the tighter carried-interval rule they use everywhere else
- * (the two agree whenever boxes bound their contents). */
+ * (the two agree whenever boxes bound their contents). Boxes of such a scene that do hold their content say so
+ * (RT_INNER_CARRIED) and keep the carried-interval rule; the flattener also puts a box of that kind, built over the
+ * whole motion of what is below, in front of every box that does not: a ray that misses it cannot hit anything
+ * below, whichever way the reference's test on the node's own box would have gone. */
 #define RT_DESC_BOXES_MAY_NOT_BOUND 1u
 
 typedef struct RtSceneDesc {

@@ -435,6 +435,11 @@ struct Hittable {  // :43-46
     virtual bool is_box6() const { return false; }
     virtual const Hittable& unwrap() const { return *this; }  // the object a chain of Translate / RotateY wraps
     virtual bool one_entry() const { return false; }          // a single primitive
+    // For the covering boxes of BVHNode (below): the hull [lo, hi] of the motion intervals of the moving spheres at or
+    // below this object is widened to hold them, and a box that holds the object for every ray time in [t0, t1],
+    // computed from the objects themselves (false: not known, behind a Translate / RotateY).
+    virtual void motion_hull(double& /*lo*/, double& /*hi*/) const {}
+    virtual bool bounds_over(double t0, double t1, AABB& out) const { return bounding_box(t0, t1, out); }
 };
 using HitPtr = std::shared_ptr<Hittable>;
 
@@ -541,6 +546,18 @@ struct HittableList : Hittable {  // :124-185
         }
         return true;
     }
+    void motion_hull(double& lo, double& hi) const override { for (const auto& o : objects) o->motion_hull(lo, hi); }
+    bool bounds_over(double t0, double t1, AABB& out) const override {
+        if (objects.empty()) return false;
+        AABB temp;
+        bool first = true;
+        for (const auto& o : objects) {
+            if (!o->bounds_over(t0, t1, temp)) return false;
+            out = first ? temp : surrounding_box(out, temp);
+            first = false;
+        }
+        return true;
+    }
 };
 
 struct MovingSphere : Hittable {  // :187-260
@@ -586,6 +603,12 @@ struct MovingSphere : Hittable {  // :187-260
         output_box = surrounding_box(box0, box1);
         return true;
     }
+    void motion_hull(double& lo, double& hi) const override {
+        if (center0.x != center1.x || center0.y != center1.y || center0.z != center1.z) {
+            lo = std::fmin(lo, std::fmin(time0, time1));
+            hi = std::fmax(hi, std::fmax(time0, time1));
+        }
+    }
 };
 
 struct Translate : Hittable {  // :262-304
@@ -595,6 +618,8 @@ struct Translate : Hittable {  // :262-304
     Translate(HitPtr p, const Vec3& displacement) : ptr(std::move(p)), offset(displacement), id(take_inst_id()) {}
     CullBox cull;
     const Hittable& unwrap() const override { return ptr->unwrap(); }
+    void motion_hull(double& lo, double& hi) const override { ptr->motion_hull(lo, hi); }
+    bool bounds_over(double, double, AABB&) const override { return false; }
     void adopted_by_bvh(double t0, double t1, bool) const override { cull.adopt(*this, t0, t1); }
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :277-292
         if (cull.culls(r, t_min, t_max)) return false;
@@ -644,6 +669,8 @@ struct RotateY : Hittable {  // :306-392
     }
     CullBox cull;
     const Hittable& unwrap() const override { return ptr->unwrap(); }
+    void motion_hull(double& lo, double& hi) const override { ptr->motion_hull(lo, hi); }
+    bool bounds_over(double, double, AABB&) const override { return false; }
     void adopted_by_bvh(double t0, double t1, bool) const override { cull.adopt(*this, t0, t1); }
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :354-387
         if (cull.culls(r, t_min, t_max)) return false;
@@ -922,6 +949,8 @@ struct ConstantMedium : Hittable {  // :10-94
     bool bounding_box(double t0, double t1, AABB& output_box) const override {  // :91-93
         return boundary->bounding_box(t0, t1, output_box);
     }
+    void motion_hull(double& lo, double& hi) const override { boundary->motion_hull(lo, hi); }
+    bool bounds_over(double t0, double t1, AABB& out) const override { return boundary->bounds_over(t0, t1, out); }
 };
 
 // ---------------------------------------------------------------------- bvh.rs
@@ -929,13 +958,52 @@ struct BVHNode : Hittable {  // :10-15
     HitPtr left, right;
     AABB _box;
     FBox fbox;
+    // Not in the reference; what the product's flattener does in scenes whose boxes may not bound their contents
+    // (AABB_PER_AXIS_F32). `holds`: every moving sphere below moves within the interval the node was built over, so the
+    // box holds its content and is tested with the carried interval. Otherwise the box is tested with the reference's
+    // per-axis rule, behind a covering box over the whole motion of what is below (carried interval, a box test of its
+    // own): a ray that misses the covering box cannot hit anything below.
+    bool holds = false, has_cover = false;
+    FBox cover;
+    void motion_hull(double& lo, double& hi) const override {
+        left->motion_hull(lo, hi);
+        if (right.get() != left.get()) right->motion_hull(lo, hi);
+    }
+    bool bounds_over(double t0, double t1, AABB& out) const override {
+        AABB a, b;
+        if (!left->bounds_over(t0, t1, a)) return false;
+        if (right.get() == left.get()) { out = a; return true; }
+        if (!right->bounds_over(t0, t1, b)) return false;
+        out = surrounding_box(a, b);
+        return true;
+    }
+    // after left, right and _box are set by BVHNode::new over (time0, time1)
+    void find_cover(double time0, double time1) {
+        double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+        motion_hull(lo, hi);
+        // the flattener keeps the node's interval as f32, rounded inward
+        holds = !(lo <= hi) || (lo >= (double)f32_up(time0) && hi <= (double)f32_down(time1));
+        AABB all;
+        has_cover = !holds && bounds_over(lo, hi, all);
+        if (!has_cover) return;
+        for (int a = 0; a < 3; ++a) {  // padded like CullBox
+            const double scale = std::fmax(std::fmax(std::fabs(all._min[a]), std::fabs(all._max[a])), all._max[a] - all._min[a]);
+            const double pad = std::fmax(scale, 1e-30) * (1.0 / 1048576.0);
+            cover.lo[a] = f32_down(all._min[a] - pad);
+            cover.hi[a] = f32_up(all._max[a] + pad);
+        }
+    }
 
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :101-111
+        if (tls.aabb_mode == AABB_PER_AXIS_F32 && has_cover && !tls.in_boundary) {
+            ++tls.n_box;
+            if (!cover.hit(r, t_min, t_max)) return false;
+        }
         ++tls.n_box;
         if (tls.aabb_mode == AABB_TIGHT) {
             if (!fbox.hit(r, t_min, t_max)) return false;
         } else if (tls.aabb_mode == AABB_PER_AXIS_F32) {
-            if (!fbox.hit_per_axis(r, t_min, t_max)) return false;
+            if (!(holds ? fbox.hit(r, t_min, t_max) : fbox.hit_per_axis(r, t_min, t_max))) return false;
         } else {
             if (!_box.hit(r, t_min, t_max)) return false;
         }
@@ -1009,6 +1077,7 @@ inline std::shared_ptr<BVHNode> new_from_list(std::vector<HitPtr>& objects, size
         throw std::runtime_error("no bounding box");  // :83-87
     temp->_box = surrounding_box(box_left, box_right);
     temp->fbox = FBox::from(temp->_box);
+    temp->find_cover(time0, time1);
     if (object_span <= 2) {  // its children are objects of the list, not nodes
         temp->left->adopted_by_bvh(time0, time1, bvh_many_boxes);
         if (temp->right.get() != temp->left.get()) temp->right->adopted_by_bvh(time0, time1, bvh_many_boxes);

@@ -388,8 +388,8 @@ RT_D bool diag_first_lane() { return (int)__lane_id() == __ffsll((unsigned long 
 // GENERAL: the scene has a ConstantMedium whose boundary is anything else than one sphere or one (wrapped) box, so the
 // re-entrant boundary walk (modes 1 and 2 and the parked world result) is needed. Without it the walker fits 128
 // registers and the kernel runs four waves per SIMD instead of three.
-// PER_AXIS: box entries are tested with the reference's per-axis rule (box_hit_per_axis) instead of the carried
-// interval; for scenes whose boxes may not bound their contents.
+// PER_AXIS: box entries not marked RT_INNER_CARRIED are tested with the reference's per-axis rule (box_hit_per_axis)
+// instead of the carried interval; for scenes whose boxes may not bound their contents.
 template <bool COUNT, bool BOXMEDIA = false, bool GENERAL = true, bool PER_AXIS = false>
 struct Walker {
     Seg g;
@@ -463,7 +463,10 @@ struct Walker {
                     if (COUNT) { work->entries++; work->prim[nb.z & 15u]++; }
 #endif
                     if ((nb.z & 15u) != RT_N_INNER) { leaf_found = true; break; }
-                    j = (PER_AXIS ? box_hit_per_axis(na, nb, g, lo, hi) : box_hit(na, nb, g, lo, hi)) ? j + 1u : nb.w;
+                    // PER_AXIS scenes: a box marked RT_INNER_CARRIED holds its content and keeps the carried interval
+                    const bool pass = !PER_AXIS ? box_hit(na, nb, g, lo, hi)
+                                                : ((nb.z >> 4) != 0u ? box_hit(na, nb, g, lo, hi) : box_hit_per_axis(na, nb, g, lo, hi));
+                    j = pass ? j + 1u : nb.w;
                     if (VOTE_DEN != 0u && (uint32_t)__popcll(__ballot(1)) * VOTE_DEN < n_in) { i = j; return false; }
                 }
                 i = j;

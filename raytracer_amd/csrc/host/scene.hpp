@@ -329,6 +329,13 @@ struct Hittable {
     // the object a chain of Translate / RotateY wraps, and whether an object is one primitive (one stream entry)
     virtual const Hittable& unwrap() const { return *this; }
     virtual bool one_entry() const { return false; }
+    // The hull of the motion intervals of the moving spheres at or below this object: [lo, hi] is widened to hold it
+    // (lo = +inf, hi = -inf: nothing below moves).
+    virtual void motion_hull(double& /*lo*/, double& /*hi*/) const {}
+    // A box that holds the object for every ray time in [t0, t1], computed from the objects themselves. Unlike
+    // bounding_box it does not stop at a BVHNode's stored box (which holds its content over the interval the node was
+    // built with only). false: not known (behind a Translate / RotateY).
+    virtual bool bounds_over(double t0, double t1, AABB& out) const { return bounding_box(t0, t1, out); }
 
 protected:
     // Where this object's row went in the flattening under way, so that an object reached twice (shared Arc in the
@@ -419,9 +426,13 @@ struct MovingSphere : Hittable {  // src/hittable.rs:187-212, 248-259
         out = surrounding_box(b0, b1);
         return true;
     }
+    bool moves() const { return center0.x != center1.x || center0.y != center1.y || center0.z != center1.z; }
+    void motion_hull(double& lo, double& hi) const override {
+        if (moves()) { lo = std::fmin(lo, std::fmin(time0, time1)); hi = std::fmax(hi, std::fmax(time0, time1)); }
+    }
     void flatten(Flat& f) const override {
         // MovingSphere::bounding_box(t0, t1) bounds the sphere for times in [t0, t1] only (src/hittable.rs:248-259)
-        const bool moves = center0.x != center1.x || center0.y != center1.y || center0.z != center1.z;
+        const bool moves = this->moves();
         if (moves && (std::fmin(time0, time1) < f.cover_t0 || std::fmax(time0, time1) > f.cover_t1)) f.boxes_may_not_bound = true;
         uint32_t idx;
         if (!flat_lookup(f, idx)) {
@@ -534,6 +545,18 @@ struct HittableList : Hittable {  // src/hittable.rs:124-185
         }
         return true;
     }
+    void motion_hull(double& lo, double& hi) const override { for (const auto& o : objects) o->motion_hull(lo, hi); }
+    bool bounds_over(double t0, double t1, AABB& out) const override {
+        if (objects.empty()) return false;
+        AABB temp;
+        bool first = true;
+        for (const auto& o : objects) {
+            if (!o->bounds_over(t0, t1, temp)) return false;
+            out = first ? temp : surrounding_box(out, temp);
+            first = false;
+        }
+        return true;
+    }
     // HittableList::hit (:151-164) keeps a running closest t over its objects in order, which is what
     // walking their entries front to back does.
     void flatten(Flat& f) const override { for (const auto& o : objects) o->flatten(f); }
@@ -568,6 +591,8 @@ struct Translate : Hittable {  // src/hittable.rs:262-304
     }
     CullBox cull;
     const Hittable& unwrap() const override { return ptr->unwrap(); }
+    void motion_hull(double& lo, double& hi) const override { ptr->motion_hull(lo, hi); }
+    bool bounds_over(double, double, AABB&) const override { return false; }
     void adopted_by_bvh(double t0, double t1, bool) const override { cull.adopt(*this, t0, t1); }
     void flatten(Flat& f) const override {
         RtXform x{};
@@ -610,6 +635,8 @@ struct RotateY : Hittable {  // src/hittable.rs:306-392
     bool bounding_box(double, double, AABB& out) const override { out = bbox; return hasbox; }
     CullBox cull;
     const Hittable& unwrap() const override { return ptr->unwrap(); }
+    void motion_hull(double& lo, double& hi) const override { ptr->motion_hull(lo, hi); }
+    bool bounds_over(double, double, AABB&) const override { return false; }
     void adopted_by_bvh(double t0, double t1, bool) const override { cull.adopt(*this, t0, t1); }
     void flatten(Flat& f) const override {
         RtXform x{};
@@ -632,6 +659,8 @@ struct ConstantMedium : Hittable {  // src/constant_medium.rs:10-31, 91-93
         : boundary(std::move(b)), phase_function(std::make_shared<Isotropic>(c)), neg_inv_density(-1.0 / d),
           id(ctx().next_prim++), rng_id(ctx().next_medium++) {}
     bool bounding_box(double t0, double t1, AABB& out) const override { return boundary->bounding_box(t0, t1, out); }
+    void motion_hull(double& lo, double& hi) const override { boundary->motion_hull(lo, hi); }
+    bool bounds_over(double t0, double t1, AABB& out) const override { return boundary->bounds_over(t0, t1, out); }
     void flatten(Flat& f) const override {
         if (f.in_medium) throw std::invalid_argument("a ConstantMedium inside the boundary of another is not supported");
         if (rng_id >= 0xFFF0u) throw std::length_error("too many ConstantMedium objects");
@@ -668,9 +697,56 @@ struct BVHNode : Hittable {  // src/bvh.rs:10-15
     float time0 = -std::numeric_limits<float>::infinity(), time1 = std::numeric_limits<float>::infinity();
     void set_times(double t0, double t1) { time0 = f32_up(t0); time1 = f32_down(t1); }
     bool bounding_box(double, double, AABB& out) const override { out = _box; return true; }  // :113-116
+    // the hull of the subtree's motion intervals, computed once
+    mutable bool hull_known = false;
+    mutable double hull_lo = 0.0, hull_hi = 0.0;
+    void motion_hull(double& lo, double& hi) const override {
+        if (!hull_known) {
+            hull_lo = std::numeric_limits<double>::infinity(); hull_hi = -hull_lo;
+            if (left) left->motion_hull(hull_lo, hull_hi);
+            if (right && right.get() != left.get()) right->motion_hull(hull_lo, hull_hi);
+            hull_known = true;
+        }
+        lo = std::fmin(lo, hull_lo); hi = std::fmax(hi, hull_hi);
+    }
+    bool bounds_over(double t0, double t1, AABB& out) const override {
+        if (!left) return false;
+        AABB a, b;
+        if (!left->bounds_over(t0, t1, a)) return false;
+        if (right.get() == left.get()) { out = a; return true; }
+        if (!right->bounds_over(t0, t1, b)) return false;
+        out = surrounding_box(a, b);
+        return true;
+    }
+    // Does the stored box hold everything below for every ray time the moving spheres below are defined for? It was
+    // built over (time0, time1) (src/bvh.rs:83-88); a MovingSphere below whose motion interval reaches outside sticks
+    // out of it (the reference's random_scene: tree over (0, 0.1), spheres moving over (0, 1), src/main.rs:315).
+    bool covered() const {
+        double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+        motion_hull(lo, hi);
+        return !(lo <= hi) || (lo >= (double)time0 && hi <= (double)time1);
+    }
     void flatten(Flat& f) const override {
         CoverScope cover(f, time0, time1);
-        const uint32_t at = f.push_node(RT_N_INNER, 0);
+        // A box that holds its content is tested with the carried interval (RT_INNER_CARRIED), also in a scene where
+        // others do not. One that may not is tested with the reference's per-axis rule, as the reference does, and gets
+        // a box in front of it that does hold the content over its whole motion (carried interval): a ray that misses
+        // that box cannot hit anything below, whatever the reference's own test says, and most rays do miss it, where
+        // the per-axis rule on its own lets nearly every ray through.
+        const bool holds = covered();
+        uint32_t cover_at = 0xFFFFFFFFu;
+        if (!holds && !f.in_medium && cull_boxes_enabled()) {
+            AABB all;
+            if (bounds_over(hull_lo, hull_hi, all)) {
+                cover_at = f.push_node(RT_N_INNER, 1);
+                for (int a = 0; a < 3; ++a) {
+                    const double pad = cull_pad(all._min[a], all._max[a]);  // see CullBox::open
+                    f.nodes[cover_at].lo[a] = f32_down(all._min[a] - pad);
+                    f.nodes[cover_at].hi[a] = f32_up(all._max[a] + pad);
+                }
+            }
+        }
+        const uint32_t at = f.push_node(RT_N_INNER, holds ? 1u : 0u);
         RtNode& n = f.nodes[at];
         // A box that is flat on an axis is never hit by the reference's test (src/aabb.rs:25, t1 <= t0);
         // rounding it outward to f32 could give it thickness, so it is stored inverted instead.
@@ -685,6 +761,7 @@ struct BVHNode : Hittable {  // src/bvh.rs:10-15
         // t_max = rec.t changes nothing, so it is emitted once.
         if (right.get() != left.get()) right->flatten(f);
         f.nodes[at].link = (uint32_t)f.nodes.size();
+        if (cover_at != 0xFFFFFFFFu) f.nodes[cover_at].link = (uint32_t)f.nodes.size();
     }
     static std::shared_ptr<BVHNode> create(HittableList& list, double time0, double time1);  // BVHNode::new, :94-97
 };
@@ -819,6 +896,15 @@ struct DeviceBvh : BVHNode {  // left / right stay empty: the tree is made on th
     std::vector<HitPtr> objects;
     double t0 = 0.0, t1 = 0.0;
     mutable double ms_device = 0.0;
+    void motion_hull(double& lo, double& hi) const override { for (const auto& o : objects) o->motion_hull(lo, hi); }
+    bool bounds_over(double a, double b, AABB& out) const override {
+        AABB temp;
+        for (size_t i = 0; i < objects.size(); ++i) {
+            if (!objects[i]->bounds_over(a, b, temp)) return false;
+            out = i ? surrounding_box(out, temp) : temp;
+        }
+        return !objects.empty();
+    }
 
     void boxes_of(std::vector<double>& boxes, AABB* whole) const {
         boxes.resize(objects.size() * 6);

@@ -128,6 +128,7 @@ int validate(const RtSceneDesc* d) {
         const uint32_t kind = n.meta & 15u, idx = n.meta >> 4;
         if (kind > RT_N_MEDIUM) return bad("entry kind");
         if (kind != RT_N_INNER && idx >= table_n[kind]) return bad("entry -> table index");
+        if (kind == RT_N_INNER && idx > RT_INNER_CARRIED) return bad("box entry with an unknown marker");
         if (medium_end && i >= medium_end) medium_end = 0;
         if (kind == RT_N_INNER || kind == RT_N_MEDIUM) {
             if (n.link <= i || n.link > d->n_nodes) return bad("entry link");
