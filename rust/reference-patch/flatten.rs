@@ -43,6 +43,7 @@ use crate::triangle::Triangle;
 use crate::vec3::Vec3;
 
 const RT_N_INNER: u32 = 0;
+const RT_INNER_CARRIED: u32 = 1;                                           // include/rt/abi.h
 const RT_N_SPHERE: u32 = 1;
 const RT_N_MSPHERE: u32 = 2;
 const RT_N_RECT: u32 = 3;
@@ -159,9 +160,32 @@ pub fn flatten_triangle(t: &Triangle, f: &mut Flat) {                       // s
         p0: a3(&t.point0), e1: a3(&(t.point1 - t.point0)), e2: a3(&(t.point2 - t.point0)), mat: t.mp.describe(f), prim_id: f.prim_id() });
 }
 pub fn flatten_list(l: &HittableList, f: &mut Flat) { for o in &l.objects { o.flatten(f); } }   // visit order of :151-164
+/// 2^-20 of a box's size and position: no face of the content may coincide with a face of a box put in front of it.
+fn cull_pad(mn: f64, mx: f64) -> f64 { mn.abs().max(mx.abs()).max(mx - mn).max(1e-30) / 1048576.0 }
+/// `full_bounds`: one more method to add to `trait Hittable` (default `None`): the box that holds the object over the
+/// whole motion of every MovingSphere inside it (`bounding_box(time0, time1)` of each sphere's own interval, the plain
+/// `bounding_box` of everything static, the union for lists and BVHNodes; `None` behind a Translate / RotateY). A node
+/// whose stored box (built over the interval BVHNode::new was given, src/bvh.rs:83-88) contains it is marked
+/// RT_INNER_CARRIED: the kernels may test it with the carried interval. One whose box does not (random_scene,
+/// src/main.rs:315) keeps the reference's per-axis test and gets a marked box with the full bounds in front of it.
+/// Restates `BVHNode::flatten` of raytracer_amd/csrc/host/scene.hpp, which decides the same from the time intervals.
 pub fn flatten_bvh(n: &BVHNode, f: &mut Flat) {                             // src/bvh.rs:11-15, 101-111
-    let at = f.push_node(RT_N_INNER, 0);
     let (mn, mx) = (a3(&n._box._min), a3(&n._box._max));
+    let full = n.full_bounds();
+    let holds = match full { Some((lo, hi)) => (0..3).all(|a| lo[a] >= mn[a] && hi[a] <= mx[a]), None => false };
+    let mut cover = None;
+    if !holds {
+        if let Some((lo, hi)) = full {
+            let c = f.push_node(RT_N_INNER, RT_INNER_CARRIED);
+            for a in 0..3 {                                                  // padded, then rounded outward
+                let pad = cull_pad(lo[a], hi[a]);
+                f.nodes[c].lo[a] = f32_down(lo[a] - pad);
+                f.nodes[c].hi[a] = f32_up(hi[a] + pad);
+            }
+            cover = Some(c);
+        }
+    }
+    let at = f.push_node(RT_N_INNER, if holds { RT_INNER_CARRIED } else { 0 });
     // a box flat on an axis is never hit (src/aabb.rs:25): stored inverted instead of rounded outward
     let flat = (0..3).any(|a| mn[a] == mx[a]);
     for a in 0..3 {
@@ -173,6 +197,7 @@ pub fn flatten_bvh(n: &BVHNode, f: &mut Flat) {                             // s
     if !Arc::ptr_eq(&n.left, &n.right) { n.right.flatten(f); }              // span-1 node holds one object twice (:39-44)
     f.enclosing = outer;
     f.nodes[at].link = f.nodes.len() as u32;
+    if let Some(c) = cover { f.nodes[c].link = f.nodes.len() as u32; }
 }
 /// A tree built by `rt_bvh_build` on the GPU instead of `BVHNode::new` (src/bvh.rs:17-98): the object list and the
 /// tree as pre-order tokens. It implements `Hittable` only to be flattened and bounded; `hit` is never called on
