@@ -53,11 +53,17 @@ enum RtError {
  *   meta = kind | index << 4
  *   RT_N_INNER   : lo/hi = box of a BVHNode (src/bvh.rs:14), link = entry to
  *                  continue at when the box is missed (one past its subtree);
- *                  index = 0, or RT_INNER_CARRIED (1): the box is known to hold
- *                  everything in its subtree for every ray time. Only looked at
- *                  in a scene flagged RT_DESC_BOXES_MAY_NOT_BOUND, where such a
- *                  box is tested with the carried interval like the boxes of any
- *                  other scene, and the others with the reference's per-axis rule
+ *                  index = 0; or RT_INNER_CARRIED (1): the box of a BVHNode that
+ *                  holds everything in its subtree while the moving spheres are
+ *                  within their motion intervals; or RT_INNER_COVER (2): a box
+ *                  that is not the reference's, put in front of a node whose own
+ *                  box does not hold its subtree, and that does. Only looked at
+ *                  in a scene flagged RT_DESC_BOXES_MAY_NOT_BOUND: for a ray whose
+ *                  time lies within the motion interval of every moving sphere of
+ *                  the scene, boxes 1 and 2 are tested with the carried interval
+ *                  like the boxes of any other scene; box 0, and box 1 for any
+ *                  other ray, with the reference's per-axis rule; box 2 lets any
+ *                  other ray pass
  *   RT_N_SPHERE .. RT_N_TRIANGLE : index into the matching primitive table
  *   RT_N_XF_ENTER: index into xforms; the ray is moved into the wrapper's
  *                  object space (src/hittable.rs:278-282, 355-368)
@@ -73,6 +79,7 @@ typedef struct RtNode {
 } RtNode;
 
 #define RT_INNER_CARRIED 1u
+#define RT_INNER_COVER 2u
 
 enum RtNodeKind {
     RT_N_INNER = 0, RT_N_SPHERE = 1, RT_N_MSPHERE = 2, RT_N_RECT = 3, RT_N_BOX6 = 4,

@@ -146,7 +146,7 @@ uint32_t orc_scene_prim_count(const OrcScene* s) { return s->ctx.next_prim; }
 // world.hit for n rays (src/color.rs:41). rec_out may be NULL.
 int orc_trace(OrcScene* s, const RtRay* rays, uint64_t n, uint64_t seed, int aabb_mode, RtHit* out, RtHitRecord* rec_out,
               uint64_t* stats) {
-    tls.aabb_mode = aabb_mode;
+    tls.aabb_mode = aabb_mode; tls.carried_t0 = s->ctx.carried_t0; tls.carried_t1 = s->ctx.carried_t1;
     tls.rng.seed = seed;
     reset_stats();
     for (uint64_t i = 0; i < n; ++i) {
@@ -193,7 +193,7 @@ int orc_render(OrcScene* s, const RtCamera* cam_in, const RtRenderParams* p, int
         const uint32_t start = (uint32_t)((uint64_t)i * W / (uint64_t)threads);
         const uint32_t end = (uint32_t)((uint64_t)(i + 1) * W / (uint64_t)threads);
         pool.emplace_back([=, &tstats]() {
-            tls.aabb_mode = aabb_mode;
+            tls.aabb_mode = aabb_mode; tls.carried_t0 = s->ctx.carried_t0; tls.carried_t1 = s->ctx.carried_t1;
             tls.rng.seed = p->seed;
             tls.recorder = nullptr;
             reset_stats();
@@ -221,7 +221,7 @@ int orc_render(OrcScene* s, const RtCamera* cam_in, const RtRenderParams* p, int
 // One iteration of ray_color (src/color.rs:41-62) per ray: the checker of rt_path_step. The ray's (pixel, sample,
 // bounce) key the medium draw inside world.hit and the scatter stream, as in ray_color above.
 int orc_path_step(OrcScene* s, const RtRenderParams* p, int aabb_mode, const RtRay* rays, uint64_t n, RtPathStep* out) {
-    tls.aabb_mode = aabb_mode;
+    tls.aabb_mode = aabb_mode; tls.carried_t0 = s->ctx.carried_t0; tls.carried_t1 = s->ctx.carried_t1;
     tls.rng.seed = p->seed;
     const Color background(p->background[0], p->background[1], p->background[2]);
     for (uint64_t i = 0; i < n; ++i) {
@@ -260,7 +260,7 @@ int orc_harvest(OrcScene* s, const RtCamera* cam_in, const RtRenderParams* p, in
     const Color background(p->background[0], p->background[1], p->background[2]);
     const uint64_t npix = (uint64_t)p->width * p->height;
     std::vector<RayRecord> rec;
-    tls.aabb_mode = aabb_mode;
+    tls.aabb_mode = aabb_mode; tls.carried_t0 = s->ctx.carried_t0; tls.carried_t1 = s->ctx.carried_t1;
     tls.rng.seed = p->seed;
     tls.recorder = &rec;
     tls.record_max_bounce = max_bounce;

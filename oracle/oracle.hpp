@@ -58,6 +58,7 @@ struct Tls {
     RngCtx rng;
     uint32_t pixel = 0, sample = 0, bounce = 0;
     int aabb_mode = AABB_REFERENCE;
+    double carried_t0 = -std::numeric_limits<double>::infinity(), carried_t1 = std::numeric_limits<double>::infinity();  // SceneCtx's
     uint64_t n_box = 0;              // BVHNode box tests
     uint64_t n_prim[K_NKINDS] = {};  // primitive hit() calls by kind
     uint64_t n_rays = 0;             // world.hit queries issued by ray_color
@@ -419,6 +420,8 @@ struct HitRecord {  // :11-19 (+ identification of the winning object for parity
 // Creation-order id counters of the scene being built (one per thread at a time).
 struct SceneCtx {
     uint32_t next_prim = 0, next_inst = 0, next_medium = 0, next_mat = 0;
+    // the ray times for which every moving sphere of the scene is within its own motion interval (see BVHNode)
+    double carried_t0 = -std::numeric_limits<double>::infinity(), carried_t1 = std::numeric_limits<double>::infinity();
 };
 inline thread_local SceneCtx* cur_ctx = nullptr;
 inline uint32_t take_prim_id() { return cur_ctx ? cur_ctx->next_prim++ : 0; }
@@ -567,7 +570,12 @@ struct MovingSphere : Hittable {  // :187-260
     MatPtr mat_ptr;
     uint32_t id;
     MovingSphere(Point cen0, Point cen1, double t0, double t1, double r, MatPtr m)
-        : center0(cen0), center1(cen1), time0(t0), time1(t1), radius(r), mat_ptr(std::move(m)), id(take_prim_id()) {}
+        : center0(cen0), center1(cen1), time0(t0), time1(t1), radius(r), mat_ptr(std::move(m)), id(take_prim_id()) {
+        if (cur_ctx && (cen0.x != cen1.x || cen0.y != cen1.y || cen0.z != cen1.z)) {
+            cur_ctx->carried_t0 = std::fmax(cur_ctx->carried_t0, std::fmin(t0, t1));
+            cur_ctx->carried_t1 = std::fmin(cur_ctx->carried_t1, std::fmax(t0, t1));
+        }
+    }
     Point center(double time) const {  // :208-211
         return center0 + (center1 - center0) * ((time - time0) / (time1 - time0));
     }
@@ -962,7 +970,10 @@ struct BVHNode : Hittable {  // :10-15
     // (AABB_PER_AXIS_F32). `holds`: every moving sphere below moves within the interval the node was built over, so the
     // box holds its content and is tested with the carried interval. Otherwise the box is tested with the reference's
     // per-axis rule, behind a covering box over the whole motion of what is below (carried interval, a box test of its
-    // own): a ray that misses the covering box cannot hit anything below.
+    // own): a ray that misses the covering box cannot hit anything below. Both only for rays whose time lies within the
+    // motion interval of every moving sphere of the scene (tls.carried_t0 .. t1): outside it MovingSphere::center
+    // extrapolates (src/hittable.rs:208-211) and no box built over the motion holds; such a ray gets the reference's
+    // per-axis test on every node and passes every covering box.
     bool holds = false, has_cover = false;
     FBox cover;
     void motion_hull(double& lo, double& hi) const override {
@@ -995,15 +1006,16 @@ struct BVHNode : Hittable {  // :10-15
     }
 
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :101-111
+        const bool in_motion = r.tm >= tls.carried_t0 && r.tm <= tls.carried_t1;
         if (tls.aabb_mode == AABB_PER_AXIS_F32 && has_cover && !tls.in_boundary) {
             ++tls.n_box;
-            if (!cover.hit(r, t_min, t_max)) return false;
+            if (in_motion && !cover.hit(r, t_min, t_max)) return false;
         }
         ++tls.n_box;
         if (tls.aabb_mode == AABB_TIGHT) {
             if (!fbox.hit(r, t_min, t_max)) return false;
         } else if (tls.aabb_mode == AABB_PER_AXIS_F32) {
-            if (!(holds ? fbox.hit(r, t_min, t_max) : fbox.hit_per_axis(r, t_min, t_max))) return false;
+            if (!(holds && in_motion ? fbox.hit(r, t_min, t_max) : fbox.hit_per_axis(r, t_min, t_max))) return false;
         } else {
             if (!_box.hit(r, t_min, t_max)) return false;
         }

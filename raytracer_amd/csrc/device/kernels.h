@@ -127,6 +127,7 @@ RT_D SceneT<true> stage_scene(const DevScene& S, const LdsPlan& plan) {
     L.images = S.images;
     L.texels = S.texels;
     L.n_nodes = S.n_nodes;
+    L.carried_t0 = S.carried_t0; L.carried_t1 = S.carried_t1;
     __syncthreads();
     return L;
 }

@@ -46,6 +46,7 @@ struct SceneT {
     const RtImage* images;
     const uint8_t* texels;
     uint32_t n_nodes;
+    double carried_t0, carried_t1;  // ray times for which boxes marked RT_INNER_CARRIED / RT_INNER_COVER hold (PER_AXIS scenes)
 };
 using DevScene = SceneT<false>;
 
@@ -463,9 +464,21 @@ struct Walker {
                     if (COUNT) { work->entries++; work->prim[nb.z & 15u]++; }
 #endif
                     if ((nb.z & 15u) != RT_N_INNER) { leaf_found = true; break; }
-                    // PER_AXIS scenes: a box marked RT_INNER_CARRIED holds its content and keeps the carried interval
-                    const bool pass = !PER_AXIS ? box_hit(na, nb, g, lo, hi)
-                                                : ((nb.z >> 4) != 0u ? box_hit(na, nb, g, lo, hi) : box_hit_per_axis(na, nb, g, lo, hi));
+                    // PER_AXIS scenes: boxes marked RT_INNER_CARRIED / RT_INNER_COVER hold their content while the moving
+                    // spheres are within their motion intervals and are tested with the carried interval for rays of
+                    // such times; for other rays a covering box is no obstacle and a node gets the reference's test
+                    bool pass;
+                    if constexpr (!PER_AXIS) {
+                        pass = box_hit(na, nb, g, lo, hi);
+                    } else {
+                        // (whether the ray's time lies within the motion intervals is looked up from tm when a marked box is
+                        // met: a flag kept per lane costs a register the kernel does not have)
+                        const uint32_t mark = nb.z >> 4;
+                        if (mark != 0u && tm >= S.carried_t0 && tm <= S.carried_t1) pass = box_hit(na, nb, g, lo, hi);
+                        // two divergent regions, not three (a region of its own for "covering box, ray out of motion:
+                        // pass" cost 24 % of the kernel on the reference's random_scene)
+                        else pass = box_hit_per_axis(na, nb, g, lo, hi) || mark == RT_INNER_COVER;
+                    }
                     j = pass ? j + 1u : nb.w;
                     if (VOTE_DEN != 0u && (uint32_t)__popcll(__ballot(1)) * VOTE_DEN < n_in) { i = j; return false; }
                 }

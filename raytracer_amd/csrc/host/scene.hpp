@@ -738,7 +738,7 @@ struct BVHNode : Hittable {  // src/bvh.rs:10-15
         if (!holds && !f.in_medium && cull_boxes_enabled()) {
             AABB all;
             if (bounds_over(hull_lo, hull_hi, all)) {
-                cover_at = f.push_node(RT_N_INNER, 1);
+                cover_at = f.push_node(RT_N_INNER, RT_INNER_COVER);
                 for (int a = 0; a < 3; ++a) {
                     const double pad = cull_pad(all._min[a], all._max[a]);  // see CullBox::open
                     f.nodes[cover_at].lo[a] = f32_down(all._min[a] - pad);
@@ -746,7 +746,7 @@ struct BVHNode : Hittable {  // src/bvh.rs:10-15
                 }
             }
         }
-        const uint32_t at = f.push_node(RT_N_INNER, holds ? 1u : 0u);
+        const uint32_t at = f.push_node(RT_N_INNER, holds ? RT_INNER_CARRIED : 0u);
         RtNode& n = f.nodes[at];
         // A box that is flat on an axis is never hit by the reference's test (src/aabb.rs:25, t1 <= t0);
         // rounding it outward to f32 could give it thickness, so it is stored inverted instead.

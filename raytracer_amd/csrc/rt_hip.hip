@@ -128,7 +128,7 @@ int validate(const RtSceneDesc* d) {
         const uint32_t kind = n.meta & 15u, idx = n.meta >> 4;
         if (kind > RT_N_MEDIUM) return bad("entry kind");
         if (kind != RT_N_INNER && idx >= table_n[kind]) return bad("entry -> table index");
-        if (kind == RT_N_INNER && idx > RT_INNER_CARRIED) return bad("box entry with an unknown marker");
+        if (kind == RT_N_INNER && idx > RT_INNER_COVER) return bad("box entry with an unknown marker");
         if (medium_end && i >= medium_end) medium_end = 0;
         if (kind == RT_N_INNER || kind == RT_N_MEDIUM) {
             if (n.link <= i || n.link > d->n_nodes) return bad("entry link");
@@ -556,6 +556,14 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         if ((rc = upload(s, d->images, d->n_images, &s->S.images))) break;
         if ((rc = upload(s, d->texels, d->n_texel_bytes, &s->S.texels))) break;
         s->S.n_nodes = (uint32_t)d->n_nodes;
+        // the ray times for which every moving sphere is within its own motion interval (RT_INNER_CARRIED / _COVER)
+        s->S.carried_t0 = -rtd::D_INF; s->S.carried_t1 = rtd::D_INF;
+        for (uint64_t i = 0; i < d->n_msphere; ++i) {
+            const RtMovingSphere& m = d->msphere[i];
+            if (m.c0[0] == m.c1[0] && m.c0[1] == m.c1[1] && m.c0[2] == m.c1[2]) continue;
+            s->S.carried_t0 = std::fmax(s->S.carried_t0, std::fmin(m.t0, m.t1));
+            s->S.carried_t1 = std::fmin(s->S.carried_t1, std::fmax(m.t0, m.t1));
+        }
     } while (0);
     if (rc) { rt_scene_destroy(s); return rc; }
     *out = s;

@@ -44,6 +44,7 @@ use crate::vec3::Vec3;
 
 const RT_N_INNER: u32 = 0;
 const RT_INNER_CARRIED: u32 = 1;                                           // include/rt/abi.h
+const RT_INNER_COVER: u32 = 2;
 const RT_N_SPHERE: u32 = 1;
 const RT_N_MSPHERE: u32 = 2;
 const RT_N_RECT: u32 = 3;
@@ -167,7 +168,7 @@ fn cull_pad(mn: f64, mx: f64) -> f64 { mn.abs().max(mx.abs()).max(mx - mn).max(1
 /// `bounding_box` of everything static, the union for lists and BVHNodes; `None` behind a Translate / RotateY). A node
 /// whose stored box (built over the interval BVHNode::new was given, src/bvh.rs:83-88) contains it is marked
 /// RT_INNER_CARRIED: the kernels may test it with the carried interval. One whose box does not (random_scene,
-/// src/main.rs:315) keeps the reference's per-axis test and gets a marked box with the full bounds in front of it.
+/// src/main.rs:315) keeps the reference's per-axis test and gets a box with the full bounds, marked RT_INNER_COVER, in front of it.
 /// Restates `BVHNode::flatten` of raytracer_amd/csrc/host/scene.hpp, which decides the same from the time intervals.
 pub fn flatten_bvh(n: &BVHNode, f: &mut Flat) {                             // src/bvh.rs:11-15, 101-111
     let (mn, mx) = (a3(&n._box._min), a3(&n._box._max));
@@ -176,7 +177,7 @@ pub fn flatten_bvh(n: &BVHNode, f: &mut Flat) {                             // s
     let mut cover = None;
     if !holds {
         if let Some((lo, hi)) = full {
-            let c = f.push_node(RT_N_INNER, RT_INNER_CARRIED);
+            let c = f.push_node(RT_N_INNER, RT_INNER_COVER);
             for a in 0..3 {                                                  // padded, then rounded outward
                 let pad = cull_pad(lo[a], hi[a]);
                 f.nodes[c].lo[a] = f32_down(lo[a] - pad);

@@ -281,6 +281,46 @@ def test_boxes_that_do_not_bound_their_spheres(gpu, orc):
     orc.api.scene_free(roots[1])
 
 
+def test_covering_boxes_in_nested_trees(gpu, orc):
+    # Covering boxes where the decision is not the same for every node: an inner tree built over the whole motion
+    # (0, 1) (its boxes hold) inside an outer tree built over (0, 0.1) (its boxes do not), moving spheres behind a
+    # Translate and a RotateY (no bounds known through a wrapper: per-axis test without a covering box), a tree built on
+    # the device among them (left as it is), spheres that move over (0.2, 0.7) only, and static objects.
+    rng = np.random.default_rng(2024)
+    n_obj = 90
+    cs = rng.uniform(-5, 5, (n_obj, 3))
+    mv = rng.uniform(-1.2, 1.2, (n_obj, 3))
+    roots = []
+    for api in (gpu.host, orc.api):
+        b = api.builder(seed=21)
+        m = b.lambertian([0.5, 0.5, 0.5])
+        def ball(k, t0=0.0, t1=1.0):
+            return b.moving_sphere(cs[k], cs[k] + mv[k], t0, t1, 0.35, m)
+        inner = b.bvh(b.list([ball(k) if k % 2 else b.sphere(cs[k], 0.3, m) for k in range(0, 30)]), 0.0, 1.0)
+        wrapped = b.translate(b.rotate_y(b.bvh(b.list([ball(k) for k in range(30, 40)]), 0.0, 0.1), 25.0), [0.5, -0.25, 1.0])
+        device = b.bvh_lbvh(b.list([ball(k) if k % 3 else b.sphere(cs[k], 0.3, m) for k in range(40, 60)]), 0.0, 0.1)
+        loose = [ball(k, 0.2, 0.7) if k % 2 else b.triangle(cs[k] + [0.8, 0, 0.1], cs[k] + [0, 0.8, -0.2], cs[k], m) for k in range(60, 90)]
+        roots.append(b.finish(b.bvh(b.list([inner, wrapped, device] + loose), 0.0, 0.1)))
+    hs = lib.HostScene(gpu, roots[0])
+    assert hs.desc.flags & abi.RT_DESC_BOXES_MAY_NOT_BOUND
+    nodes = hs.table("nodes")
+    inner_entries = nodes[(nodes["meta"] & 15) == abi.RT_N_INNER]
+    assert set((inner_entries["meta"] >> 4).tolist()) == {0, 1, 2}  # plain, holding and covering boxes are all there
+    ds = lib.DeviceScene(hs)
+    rays = random_rays(rng, 30000)
+    oh, _, ost = orc.trace(roots[1], rays, seed=9, mode=oracle.AABB_PER_AXIS_F32)
+    gh, work = ds.trace_work(rays, seed=9)
+    d = compare_hits(oh, gh, "covering boxes, nested trees")
+    assert d.max(initial=0) == 0 and work["inner"] == ost["box_tests"] and work["msphere"] == ost["msphere"]
+    # the reference as written (f64 boxes, no covering boxes) finds the same hits but for rays within a rounding of a face
+    ref, _, rst = orc.trace(roots[1], rays, seed=9, mode=oracle.AABB_REFERENCE)
+    assert (ref["prim_id"] != oh["prim_id"]).sum() <= 2
+    assert ost["msphere"] < rst["msphere"]  # ... with fewer sphere tests
+    ds.close()
+    hs.close()
+    orc.api.scene_free(roots[1])
+
+
 def test_edge_cases(gpu, orc):
     b = gpu.host.builder()
     ob = orc.api.builder()

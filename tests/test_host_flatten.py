@@ -40,21 +40,21 @@ def test_flatten_structure(rtlib, orc, sid):
     # a leaf of a tree, or for a box of six sides that is one (not in the reference): one child, padded slightly beyond
     # the child's own box.
     # In a scene whose boxes may not hold their contents (scene 1: tree over (0, 0.1), spheres moving over (0, 1)) a node
-    # whose box may not gets a covering box in front of it (marked RT_INNER_CARRIED, one child: the node, unmarked), over
+    # whose box may not gets a covering box in front of it (marked RT_INNER_COVER, one child: the node, unmarked), over
     # the whole motion of what is below; nodes whose box does hold are marked themselves.
     def plain_cull(i):  # a box entry with exactly one child that is a wrapper or a box of six sides
         return kinds[i + 1] in (K["xf_enter"], K["box6"]) and walk_subtree_end(nodes, i + 1) == int(nodes["link"][i])
 
     def is_cover(i):
-        return (kinds[i + 1] == K["inner"] and idx[i] == 1 and idx[i + 1] == 0 and nodes["link"][i] == nodes["link"][i + 1]
-                and not plain_cull(i + 1))
+        return idx[i] == 2 and kinds[i + 1] == K["inner"] and idx[i + 1] == 0 and nodes["link"][i] == nodes["link"][i + 1]
 
     def is_cull(i):
         return is_cover(i) or plain_cull(i)
 
     inner = np.nonzero(kinds == K["inner"])[0]
-    assert set(idx[inner].tolist()) <= {0, 1}
-    n_cover = sum(1 for i in inner if i + 2 < n and is_cover(i))
+    assert set(idx[inner].tolist()) <= {0, 1, 2}
+    n_cover = sum(1 for i in inner if i + 1 < n and is_cover(i))
+    assert n_cover == int((idx[inner] == 2).sum())
     if hs.desc.flags & abi.RT_DESC_BOXES_MAY_NOT_BOUND:
         assert n_cover > 0
     else:
