@@ -138,7 +138,11 @@ typedef struct RtImage {         /* src/texture.rs:75-79; texels are RGB u8 rows
  * (the two agree whenever boxes bound their contents). Boxes of such a scene that do hold their content say so
  * (RT_INNER_CARRIED) and keep the carried-interval rule; the flattener also puts a box of that kind, built over the
  * whole motion of what is below, in front of every box that does not: a ray that misses it cannot hit anything
- * below, whichever way the reference's test on the node's own box would have gone. */
+ * below, whichever way the reference's test on the node's own box would have gone.
+ * A scene without the flag is walked with the carried interval throughout, which takes every ray's time to lie within
+ * the motion interval of every MovingSphere (true of the reference's cameras and scenes: both run over the shutter):
+ * MovingSphere::center extrapolates outside that interval (src/hittable.rs:208-211), out of the boxes built for it,
+ * where the reference's per-axis rule may still find the sphere and the carried interval does not. */
 #define RT_DESC_BOXES_MAY_NOT_BOUND 1u
 
 typedef struct RtSceneDesc {
