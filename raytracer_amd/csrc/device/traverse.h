@@ -464,20 +464,33 @@ struct Walker {
                     if (COUNT) { work->entries++; work->prim[nb.z & 15u]++; }
 #endif
                     if ((nb.z & 15u) != RT_N_INNER) { leaf_found = true; break; }
-                    // PER_AXIS scenes: boxes marked RT_INNER_CARRIED / RT_INNER_COVER hold their content while the moving
-                    // spheres are within their motion intervals and are tested with the carried interval for rays of
-                    // such times; for other rays a covering box is no obstacle and a node gets the reference's test
                     bool pass;
                     if constexpr (!PER_AXIS) {
                         pass = box_hit(na, nb, g, lo, hi);
                     } else {
-                        // (whether the ray's time lies within the motion intervals is looked up from tm when a marked box is
-                        // met: a flag kept per lane costs a register the kernel does not have)
-                        const uint32_t mark = nb.z >> 4;
-                        if (mark != 0u && tm >= S.carried_t0 && tm <= S.carried_t1) pass = box_hit(na, nb, g, lo, hi);
-                        // two divergent regions, not three (a region of its own for "covering box, ray out of motion:
-                        // pass" cost 24 % of the kernel on the reference's random_scene)
-                        else pass = box_hit_per_axis(na, nb, g, lo, hi) || mark == RT_INNER_COVER;
+                        // PER_AXIS scenes: boxes marked RT_INNER_CARRIED / RT_INNER_COVER hold their content while the moving
+                        // spheres are within their motion intervals and are tested with the carried interval for rays of
+                        // such times; for other rays a covering box is no obstacle and a node gets the reference's test.
+                        // (Whether the ray's time lies within the motion intervals is looked up from tm: a flag kept per
+                        // lane costs a register the kernel does not have.)
+                        uint32_t mark = nb.z >> 4;
+                        const bool in_motion = tm >= S.carried_t0 && tm <= S.carried_t1;
+                        pass = true;
+                        if (mark != 0u && in_motion) pass = box_hit(na, nb, g, lo, hi);
+                        // A covering box that lets the ray pass is followed by the node it covers, an unmarked box entry,
+                        // which is tested in the same round: lanes on covering boxes and lanes on nodes would otherwise
+                        // drift apart and every round would run both tests for half of the lanes each.
+                        if (mark == RT_INNER_COVER && pass) {
+                            ++j;
+                            load_node(S.nodes + j, na, nb);
+#ifdef RT_DIAG_WAVE
+                            if (COUNT && diag_first_lane()) { work->entries++; work->prim[RT_N_INNER]++; }
+#else
+                            if (COUNT) { work->entries++; work->prim[RT_N_INNER]++; }
+#endif
+                            mark = 0u;
+                        }
+                        if (mark == 0u || (mark == RT_INNER_CARRIED && !in_motion)) pass = box_hit_per_axis(na, nb, g, lo, hi);
                     }
                     j = pass ? j + 1u : nb.w;
                     if (VOTE_DEN != 0u && (uint32_t)__popcll(__ballot(1)) * VOTE_DEN < n_in) { i = j; return false; }

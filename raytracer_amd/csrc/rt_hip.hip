@@ -129,6 +129,10 @@ int validate(const RtSceneDesc* d) {
         if (kind > RT_N_MEDIUM) return bad("entry kind");
         if (kind != RT_N_INNER && idx >= table_n[kind]) return bad("entry -> table index");
         if (kind == RT_N_INNER && idx > RT_INNER_COVER) return bad("box entry with an unknown marker");
+        if (kind == RT_N_INNER && idx == RT_INNER_COVER) {  // the walk steps from a covering box straight onto the node it covers
+            if (i + 1 >= d->n_nodes || d->nodes[i + 1].meta != RT_N_INNER || d->nodes[i + 1].link != n.link)
+                return bad("covering box not followed by the unmarked box entry it covers");
+        }
         if (medium_end && i >= medium_end) medium_end = 0;
         if (kind == RT_N_INNER || kind == RT_N_MEDIUM) {
             if (n.link <= i || n.link > d->n_nodes) return bad("entry link");
