@@ -82,4 +82,6 @@ extern "C" {
 pub const RT_BVH_TOKEN_LEAF: u32 = 0xF;
 pub const RT_BVH_NOALLOC_MAX_OBJECTS: u32 = 65536;
 pub const RT_DESC_BOXES_MAY_NOT_BOUND: u32 = 1;
+pub const RT_INNER_CARRIED: u32 = 1;
+pub const RT_INNER_COVER: u32 = 2;
 pub const RT_PROFILE_OWN: c_int = -1;

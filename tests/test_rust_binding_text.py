@@ -120,8 +120,11 @@ def test_rust_declarations_match_the_header():
     assert len(cf) >= 24 and len(cs) >= 21
     # constants both sides name
     for cname, pattern in (("RT_BVH_TOKEN_LEAF", r"RT_BVH_TOKEN_LEAF 0xFu"), ("RT_BVH_NOALLOC_MAX_OBJECTS", r"RT_BVH_NOALLOC_MAX_OBJECTS 65536u"),
-                           ("RT_DESC_BOXES_MAY_NOT_BOUND", r"RT_DESC_BOXES_MAY_NOT_BOUND 1u")):
+                           ("RT_DESC_BOXES_MAY_NOT_BOUND", r"RT_DESC_BOXES_MAY_NOT_BOUND 1u"),
+                           ("RT_INNER_CARRIED", r"RT_INNER_CARRIED 1u"), ("RT_INNER_COVER", r"RT_INNER_COVER 2u")):
         assert re.search(pattern, header) and cname in rust, cname
+        value = int(re.search(r"#define %s (0x[0-9A-Fa-f]+|\d+)u" % cname, header).group(1), 0)
+        assert int(re.search(r"pub const %s: \w+ = (0x[0-9A-Fa-f]+|\d+);" % cname, rust).group(1), 0) == value, cname
     # the opaque handles
     for h in ("RtScene", "RtShardedScene"):
         assert re.search(r"typedef struct %s %s;" % (h, h), header) and re.search(r"pub enum %s \{\}" % h, rust)
