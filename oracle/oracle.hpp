@@ -976,6 +976,10 @@ struct BVHNode : Hittable {  // :10-15
     // per-axis test on every node and passes every covering box.
     bool holds = false, has_cover = false;
     FBox cover;
+    // A node whose box contains the world's box (the root, and in final_scene the two nodes above the fog's sphere of
+    // radius 5000) is passed by every ray that starts inside the world; the flattener gives such a node no entry, and
+    // the GPU modes here skip its test (mark_world_boxes below). Skipping a box that holds its content changes no hit.
+    bool no_entry = false;
     void motion_hull(double& lo, double& hi) const override {
         left->motion_hull(lo, hi);
         if (right.get() != left.get()) right->motion_hull(lo, hi);
@@ -1006,6 +1010,12 @@ struct BVHNode : Hittable {  // :10-15
     }
 
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :101-111
+        if (no_entry && tls.aabb_mode != AABB_REFERENCE) {
+            bool hit_left = left->hit(r, t_min, t_max, rec);
+            if (right.get() == left.get()) return hit_left;
+            bool hit_right = right->hit(r, t_min, hit_left ? rec.t : t_max, rec);
+            return hit_left || hit_right;
+        }
         const bool in_motion = r.tm >= tls.carried_t0 && r.tm <= tls.carried_t1;
         if (tls.aabb_mode == AABB_PER_AXIS_F32 && has_cover && !tls.in_boundary) {
             ++tls.n_box;
@@ -1029,6 +1039,25 @@ struct BVHNode : Hittable {  // :10-15
         return true;
     }
 };
+
+// Marks the nodes that get no entry: reached from the world's root through BVHNodes and HittableLists only (world
+// space, outside any medium boundary), holding their content, not flat on an axis, and containing the root's box.
+inline void mark_world_boxes(const HitPtr& obj, const AABB& world) {
+    if (auto* list = dynamic_cast<HittableList*>(obj.get())) {
+        for (const HitPtr& o : list->objects) mark_world_boxes(o, world);
+        return;
+    }
+    auto* node = dynamic_cast<BVHNode*>(obj.get());
+    if (!node) return;
+    bool flat = false, contains = true;
+    for (int a = 0; a < 3; ++a) {
+        flat = flat || node->_box._min[a] == node->_box._max[a];
+        contains = contains && node->_box._min[a] <= world._min[a] && node->_box._max[a] >= world._max[a];
+    }
+    node->no_entry = node->holds && !flat && contains;
+    mark_world_boxes(node->left, world);
+    if (node->right.get() != node->left.get()) mark_world_boxes(node->right, world);
+}
 
 // Boxes of six sides that are leaves of a tree get a culling box of their own (CullBox) when the list the tree is made
 // from holds at least this many of them; the product's flattener applies the same rule.

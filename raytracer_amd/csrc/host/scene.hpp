@@ -167,6 +167,10 @@ struct Flat {
     // whether some object moves outside it: its boxes then do not bound it (RT_DESC_BOXES_MAY_NOT_BOUND)
     double cover_t0 = -std::numeric_limits<double>::infinity(), cover_t1 = std::numeric_limits<double>::infinity();
     bool boxes_may_not_bound = false;
+    // the box of the first BVHNode flattened, the world's: every ray that starts on something in the scene starts
+    // inside it (see BVHNode::flatten)
+    AABB world_box;
+    bool have_world_box = false;
 
     uint32_t push_node(uint32_t kind, uint32_t index, uint32_t link = 0) {
         if (index >= (1u << 28)) throw std::length_error("table index exceeds 28 bits");
@@ -734,6 +738,23 @@ struct BVHNode : Hittable {  // src/bvh.rs:10-15
         // that box cannot hit anything below, whatever the reference's own test says, and most rays do miss it, where
         // the per-axis rule on its own lets nearly every ray through.
         const bool holds = covered();
+        // A box that contains the world's box is passed by every ray that starts inside the world (all of them but
+        // camera rays of a camera placed outside, and those it only costs the work it would have saved): the test can
+        // tell nothing, so the node gets no entry and its children take its place, as those of a HittableList would.
+        // Skipping a box that holds its content never changes a hit. Only in world space, and not for a box that is
+        // flat on an axis (the reference never hits that one, src/aabb.rs:25).
+        bool is_flat = false;
+        for (int a = 0; a < 3; ++a) is_flat = is_flat || (_box._min[a] == _box._max[a]);
+        if (!f.have_world_box) { f.world_box = _box; f.have_world_box = true; }  // the first node flattened is the world's root
+        if (holds && !is_flat && f.xf_stack.empty() && !f.in_medium && cull_boxes_enabled()) {
+            bool contains = true;
+            for (int a = 0; a < 3; ++a) contains = contains && _box._min[a] <= f.world_box._min[a] && _box._max[a] >= f.world_box._max[a];
+            if (contains) {
+                left->flatten(f);
+                if (right.get() != left.get()) right->flatten(f);
+                return;
+            }
+        }
         uint32_t cover_at = 0xFFFFFFFFu;
         if (!holds && !f.in_medium && cull_boxes_enabled()) {
             AABB all;
@@ -938,6 +959,7 @@ struct DeviceBvh : BVHNode {  // left / right stay empty: the tree is made on th
     // miss per object: 2 s for 10 M triangles.
     void flatten(Flat& f) const override {
         CoverScope cover(f, time0, time1);
+        if (!f.have_world_box) { f.world_box = _box; f.have_world_box = true; }
         std::vector<RtNode> mine;
         mine.swap(f.nodes);  // the entries before this tree; f.nodes collects the objects' entries meanwhile
         std::vector<uint32_t> offsets(objects.size() + 1);
