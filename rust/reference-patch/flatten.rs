@@ -78,6 +78,7 @@ pub struct Flat {
     /// flagged RT_DESC_BOXES_MAY_NOT_BOUND and the kernels run the per-axis box rule of src/aabb.rs:15-30
     enclosing: Option<([f64; 3], [f64; 3])>,
     pub boxes_may_not_bound: bool,
+    world_box: Option<([f64; 3], [f64; 3])>,   // box of the first BVHNode flattened, the world's root
 }
 
 impl Flat {
@@ -174,6 +175,14 @@ pub fn flatten_bvh(n: &BVHNode, f: &mut Flat) {                             // s
     let (mn, mx) = (a3(&n._box._min), a3(&n._box._max));
     let full = n.full_bounds();
     let holds = match full { Some((lo, hi)) => (0..3).all(|a| lo[a] >= mn[a] && hi[a] <= mx[a]), None => false };
+    // a node whose box contains the world's (the root first of all) is passed by every ray from inside the scene: no entry,
+    // its children take its place (world space only, not for a box flat on an axis, which the reference never hits)
+    let world = *f.world_box.get_or_insert((mn, mx));
+    if holds && f.xf_stack.is_empty() && !f.in_medium && (0..3).all(|a| mn[a] != mx[a] && mn[a] <= world.0[a] && mx[a] >= world.1[a]) {
+        n.left.flatten(f);
+        if !Arc::ptr_eq(&n.left, &n.right) { n.right.flatten(f); }
+        return;
+    }
     let mut cover = None;
     if !holds {
         if let Some((lo, hi)) = full {
