@@ -1,0 +1,124 @@
+"""The oracle's GPU box modes against the reference's own rule, at scale.
+
+The HIP kernels are compared with the oracle in the mode that mirrors what they run (carried-interval test on f32
+boxes, culling boxes, covering boxes, no entries for boxes that contain the world: AABB_TIGHT / AABB_PER_AXIS_F32).
+None of that machinery exists in the reference: BVHNode::hit (src/bvh.rs:101-111) tests every node with AABB::hit
+as written (src/aabb.rs:15-30) on f64 boxes. These tests tie the mirrored modes back to that rule on the same ray
+sets the GPU tests use: the closest hit (primitive, side / wrapper, bits of t) must not depend on the mode. A
+mistake shared by the product and the mirrored oracle mode (a culling box that does not cover, a skipped node whose
+box mattered, a tie at a padded face) shows up here as a difference from AABB_REFERENCE."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import CONFIG_SCENES, SEED, oracle_mode, scene_kwargs
+from raytracer_amd import abi, lib
+from scenegen import clipping_scene_pair, nested_cover_scene_pair, random_rays, random_scene_pair
+
+
+def same_hits(a, b, what):
+    assert np.array_equal(a["prim_id"], b["prim_id"]), what + ": primitive ids differ from the reference rule"
+    assert np.array_equal(a["sub"], b["sub"]), what + ": box sides / wrapper ids differ from the reference rule"
+    assert np.array_equal(a["t"].view(np.uint64), b["t"].view(np.uint64)), what + ": bits of t differ from the reference rule"
+    assert np.array_equal(a["u"].view(np.uint64), b["u"].view(np.uint64)) and np.array_equal(a["v"].view(np.uint64), b["v"].view(np.uint64))
+
+
+def harvested(orc, osc, sid, seed, n_paths=40000):
+    su = orc.api.scene_setup(sid)
+    cam = orc.api.camera(su)
+    W = 256
+    p = orc.make_params(W, int(W / su.aspect_ratio), 0, 4, list(su.background), seed=seed)
+    rays = orc.harvest(osc, cam, p, n_paths=n_paths, max_rays=1 << 16, max_bounce=3)
+    assert len(rays) > 30000
+    return rays, p
+
+
+@pytest.mark.parametrize("sid", CONFIG_SCENES)
+def test_config_scenes_30k_rays(orc, rtlib, sid):
+    # the seeded ray sets of tests/test_gpu_trace.py::test_seeded_ray_set_and_work_vs_oracle
+    seed = 0xC0FFEE + sid
+    kw = scene_kwargs(sid)
+    hs = lib.HostScene.build(sid, seed=seed, **kw)
+    osc = orc.api.scene_build(sid, seed=seed, **kw)
+    rays, p = harvested(orc, osc, sid, seed)
+    mode = oracle_mode(hs)
+    mine, _, st = orc.trace(osc, rays, seed=seed, mode=mode)
+    ref, _, rst = orc.trace(osc, rays, seed=seed, mode=oracle.AABB_REFERENCE)
+    if mode == oracle.AABB_PER_AXIS_F32:
+        # the reference's per-axis rule on f32 planes against the same rule on its f64 planes: a ray may pass within
+        # one f32 rounding of a face of a box that does not bound its sphere
+        assert sid == 1
+        differ = (mine["prim_id"] != ref["prim_id"]) | (mine["t"].view(np.uint64) != ref["t"].view(np.uint64))
+        assert differ.mean() <= 1e-4, differ.sum()
+    else:
+        same_hits(mine, ref, "scene %d" % sid)
+    assert st["box_tests"] < rst["box_tests"]  # ... and the mirrored mode is the cheaper one
+    # one whole iteration of ray_color (hit, emitted, scatter) does not depend on the mode either
+    a = orc.path_step(osc, p, rays, mode=mode)
+    b = orc.path_step(osc, p, rays, mode=oracle.AABB_REFERENCE)
+    if mode == oracle.AABB_TIGHT:
+        assert a.tobytes() == b.tobytes()
+    hs.close()
+    orc.api.scene_free(osc)
+
+
+def test_final_scene_with_1600_ground_boxes(orc, rtlib):
+    # boxes_per_side = 40: four times the boxes of src/main.rs:591, tables beyond what the kernels stage in LDS
+    seed = SEED
+    kw = dict(scene_kwargs(9), boxes_per_side=40)
+    hs = lib.HostScene.build(9, seed=seed, **kw)
+    osc = orc.api.scene_build(9, seed=seed, **kw)
+    rays, _ = harvested(orc, osc, 9, seed)
+    mine, _, _ = orc.trace(osc, rays, seed=seed, mode=oracle_mode(hs))
+    ref, _, _ = orc.trace(osc, rays, seed=seed, mode=oracle.AABB_REFERENCE)
+    same_hits(mine, ref, "final scene, 40 x 40 boxes")
+    hs.close()
+    orc.api.scene_free(osc)
+
+
+@pytest.mark.parametrize("tree", ["widest", "lbvh"])
+def test_mesh_with_other_tree_policies(orc, rtlib, tree):
+    # 200 000 triangles under the two optional tree policies: the rule must not matter whatever the tree
+    flags = {"widest": abi.RT_SCENE_BVH_WIDEST_AXIS, "lbvh": abi.RT_SCENE_BVH_LBVH}[tree]
+    osc = orc.api.scene_build(12, seed=SEED, flags=flags, n_triangles=200000)
+    rays, _ = harvested(orc, osc, 12, SEED, n_paths=20000)
+    mine, _, _ = orc.trace(osc, rays, seed=SEED, mode=oracle.AABB_TIGHT)
+    ref, _, _ = orc.trace(osc, rays, seed=SEED, mode=oracle.AABB_REFERENCE)
+    same_hits(mine, ref, "mesh, %s tree" % tree)
+    orc.api.scene_free(osc)
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_random_scenes_all_primitive_kinds(orc, rtlib, case):
+    # the scenes and rays of tests/test_gpu_trace.py::test_random_scenes_all_primitive_kinds, and as many rays again:
+    # wrappers around several primitives (culling boxes), media of all three boundary kinds, eight and more boxes
+    rng = np.random.default_rng(1234 + case)
+    _, (hroot, oroot) = random_scene_pair(rng, rtlib, orc, n_obj=int(rng.integers(4, 40)))
+    hs = lib.HostScene(rtlib, hroot)
+    rays = np.concatenate([random_rays(rng, 20000), random_rays(rng, 20000)])
+    mine, _, _ = orc.trace(oroot, rays, seed=77, mode=oracle_mode(hs))
+    ref, _, _ = orc.trace(oroot, rays, seed=77, mode=oracle.AABB_REFERENCE)
+    assert (ref["prim_id"] != abi.RT_MISS).sum() > 400
+    same_hits(mine, ref, "random scene %d" % case)
+    hs.close()
+    orc.api.scene_free(oroot)
+
+
+@pytest.mark.parametrize("which", ["clipping", "nested"])
+def test_scenes_whose_boxes_do_not_bound(orc, rtlib, which):
+    # the two synthetic per-axis scenes of tests/test_gpu_trace.py: covering boxes and the f32 planes must not change a
+    # hit but for rays within one f32 rounding of a face
+    rng = np.random.default_rng(99 if which == "clipping" else 2024)
+    if which == "clipping":
+        hroot, oroot = clipping_scene_pair(rng, rtlib, orc)
+        hs = lib.HostScene(rtlib, hroot)
+        assert hs.desc.flags & abi.RT_DESC_BOXES_MAY_NOT_BOUND
+        hs.close()
+    else:
+        _, oroot = nested_cover_scene_pair(rng, rtlib, orc, oracle_only=True)
+    rays = random_rays(rng, 30000)
+    mine, _, _ = orc.trace(oroot, rays, seed=5, mode=oracle.AABB_PER_AXIS_F32)
+    ref, _, _ = orc.trace(oroot, rays, seed=5, mode=oracle.AABB_REFERENCE)
+    differ = (mine["prim_id"] != ref["prim_id"]) | (mine["t"].view(np.uint64) != ref["t"].view(np.uint64))
+    assert differ.mean() <= 1e-4, differ.sum()
+    orc.api.scene_free(oroot)

@@ -10,6 +10,7 @@ import pytest
 import oracle
 from conftest import CONFIG_SCENES, SCENE_OPTS, SEED, load_golden, scene_kwargs, ulp_diff, oracle_mode
 from raytracer_amd import abi, lib
+from scenegen import clipping_scene_pair, nested_cover_scene_pair, random_rays, random_scene_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -144,68 +145,6 @@ def test_large_ray_pool(gpu, sid):
     hs.close()
 
 
-def random_scene_pair(rng, rtlib, orc, n_obj):
-    """The same random ad-hoc scene in the product builder and the oracle builder."""
-    # identical call sequence and scene-stream seed (it picks the BVH split axes) on both
-    seed = int(rng.integers(1 << 30))
-    builders = [rtlib.host.builder(seed=seed), orc.api.builder(seed=seed)]
-    roots = []
-    plan = []
-    kinds = rng.integers(0, 10, size=n_obj)
-    for k in kinds:
-        c = rng.uniform(-4, 4, 3)
-        plan.append((int(k), c, rng.uniform(0.2, 1.2), rng.uniform(-1, 1, 3), rng.uniform(-60, 60), rng.uniform(0.05, 0.8),
-                     rng.uniform(0.3, 1.5, 3), int(rng.integers(0, 3))))
-    for b in builders:
-        m = [b.lambertian([0.5, 0.5, 0.5]), b.metal([0.8, 0.7, 0.6], 0.1), b.dielectric(1.5)]
-        objs = []
-        for (k, c, r, off, ang, dens, ext, mi) in plan:
-            mat = m[mi]
-            if k == 0:
-                o = b.sphere(c, r, mat)
-            elif k == 1:
-                o = b.moving_sphere(c, c + off * 0.3, 0.0, 1.0, r * 0.5, mat)
-            elif k == 2:
-                o = [b.xy_rect, b.xz_rect, b.yz_rect][mi](c[0], c[0] + ext[0], c[1], c[1] + ext[1], c[2], mat)
-            elif k == 3:
-                o = b.box6(c, c + ext, mat)
-            elif k == 4:
-                o = b.triangle(c + [ext[0], 0, 0.1], c + [0, ext[1], -0.2], c, mat)
-            elif k == 5:
-                o = b.translate(b.rotate_y(b.box6(c, c + ext, mat), ang), off)
-            elif k == 6:
-                o = b.constant_medium(b.sphere(c, r, mat), dens, [0.9, 0.9, 0.9])
-            elif k == 7:
-                o = b.constant_medium(b.translate(b.rotate_y(b.box6(c, c + ext, mat), ang), off), dens, [0.2, 0.4, 0.9])
-            elif k == 9:  # a medium whose boundary is neither one sphere nor one wrapped box: the general boundary walk
-                o = b.constant_medium(b.translate(b.sphere(c, r, mat), off), dens, [0.7, 0.3, 0.3])
-            else:  # a nested BVH of small spheres inside rotate(translate(rotate()))
-                inner = [b.sphere(c + rng_off, 0.15, mat) for rng_off in ([0, 0, 0], [0.4, 0, 0], [0, 0.4, 0], [0, 0, 0.4], [0.4, 0.4, 0])]
-                o = b.rotate_y(b.translate(b.rotate_y(b.bvh(b.list(inner)), ang), off), -ang * 0.5)
-            objs.append(o)
-        roots.append(b.finish(b.bvh(b.list(objs), 0.0, 1.0)))
-    return builders, roots
-
-
-def random_rays(rng, n):
-    rays = np.zeros(n, dtype=abi.RAY_DTYPE)
-    rays["o"] = rng.uniform(-6, 6, (n, 3))
-    d = rng.normal(size=(n, 3)) * rng.uniform(0.1, 3.0, (n, 1))
-    axis = rng.integers(0, 8, n)  # some directions with exact zeros / axis aligned
-    d[axis == 0, 0] = 0.0
-    d[axis == 1, 1] = 0.0
-    d[axis == 2, 2] = 0.0
-    d[axis == 3, :2] = 0.0
-    rays["d"] = d
-    rays["tm"] = rng.uniform(0, 1, n)
-    rays["tmin"] = np.where(rng.uniform(size=n) < 0.8, 1e-4, rng.uniform(-2, 2, n))
-    rays["tmax"] = np.where(rng.uniform(size=n) < 0.8, np.inf, rng.uniform(0, 10, n))
-    rays["pixel"] = rng.integers(0, 1 << 20, n)
-    rays["sample"] = rng.integers(0, 1 << 10, n)
-    rays["bounce"] = rng.integers(0, 50, n)
-    return rays
-
-
 @pytest.mark.parametrize("case", range(6))
 def test_random_scenes_all_primitive_kinds(gpu, orc, case):
     rng = np.random.default_rng(1234 + case)
@@ -232,22 +171,7 @@ def test_boxes_that_do_not_bound_their_spheres(gpu, orc):
     # (src/main.rs:315): the closest hit then depends on the box rule. The flattener flags such a scene and the
     # kernels run the reference's per-axis rule (src/aabb.rs:15-30) on it; the carried-interval rule would clip.
     rng = np.random.default_rng(99)
-    roots = []
-    n_obj = 120
-    cs = rng.uniform(-5, 5, (n_obj, 3))
-    mv = rng.uniform(-1.5, 1.5, (n_obj, 3))
-    for api in (gpu.host, orc.api):
-        b = api.builder(seed=11)
-        m = b.lambertian([0.5, 0.5, 0.5])
-        objs = []
-        for k in range(n_obj):
-            if k % 3 == 0:
-                objs.append(b.sphere(cs[k], 0.4, m))
-            elif k % 3 == 1:
-                objs.append(b.moving_sphere(cs[k], cs[k] + mv[k], 0.0, 1.0, 0.35, m))
-            else:
-                objs.append(b.triangle(cs[k] + [0.8, 0, 0.1], cs[k] + [0, 0.8, -0.2], cs[k], m))
-        roots.append(b.finish(b.bvh(b.list(objs), 0.0, 0.2)))
+    roots = clipping_scene_pair(rng, gpu, orc)
     hs = lib.HostScene(gpu, roots[0])
     assert hs.desc.flags & abi.RT_DESC_BOXES_MAY_NOT_BOUND
     ds = lib.DeviceScene(hs)
@@ -287,20 +211,7 @@ def test_covering_boxes_in_nested_trees(gpu, orc):
     # Translate and a RotateY (no bounds known through a wrapper: per-axis test without a covering box), a tree built on
     # the device among them (left as it is), spheres that move over (0.2, 0.7) only, and static objects.
     rng = np.random.default_rng(2024)
-    n_obj = 90
-    cs = rng.uniform(-5, 5, (n_obj, 3))
-    mv = rng.uniform(-1.2, 1.2, (n_obj, 3))
-    roots = []
-    for api in (gpu.host, orc.api):
-        b = api.builder(seed=21)
-        m = b.lambertian([0.5, 0.5, 0.5])
-        def ball(k, t0=0.0, t1=1.0):
-            return b.moving_sphere(cs[k], cs[k] + mv[k], t0, t1, 0.35, m)
-        inner = b.bvh(b.list([ball(k) if k % 2 else b.sphere(cs[k], 0.3, m) for k in range(0, 30)]), 0.0, 1.0)
-        wrapped = b.translate(b.rotate_y(b.bvh(b.list([ball(k) for k in range(30, 40)]), 0.0, 0.1), 25.0), [0.5, -0.25, 1.0])
-        device = b.bvh_lbvh(b.list([ball(k) if k % 3 else b.sphere(cs[k], 0.3, m) for k in range(40, 60)]), 0.0, 0.1)
-        loose = [ball(k, 0.2, 0.7) if k % 2 else b.triangle(cs[k] + [0.8, 0, 0.1], cs[k] + [0, 0.8, -0.2], cs[k], m) for k in range(60, 90)]
-        roots.append(b.finish(b.bvh(b.list([inner, wrapped, device] + loose), 0.0, 0.1)))
+    roots = nested_cover_scene_pair(rng, gpu, orc)
     hs = lib.HostScene(gpu, roots[0])
     assert hs.desc.flags & abi.RT_DESC_BOXES_MAY_NOT_BOUND
     nodes = hs.table("nodes")
