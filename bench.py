@@ -22,7 +22,8 @@ anything in this process has touched the GPU, relays the child's output and exit
 
 Rank 0 prints one JSON line: whole-job samples/s, the roofline of the dominant kernel (extend: BVH closest
 hit) from HIP-event timings taken inside the timed region and algorithmic bytes counted by an instrumented
-pass outside it, and the CPU oracle timed on the host cores on a bounded sample of the same workload."""
+pass outside it, the CPU oracle timed on the host cores on a bounded sample of the same workload, and the RMSE between
+the GPU's and the oracle's pictures of that sample."""
 import argparse
 import ctypes as C
 import json
@@ -152,7 +153,10 @@ def cpu_model():
 def cpu_baseline(wl, spp, threads, more_threads=0, bvh="reference"):
     """The CPU oracle (oracle/, a C++ restatement of the reference) on the same scene and image size, `spp`
     samples per pixel, `threads` std::threads splitting columns as src/main.rs:193-195 does; when `more_threads`
-    is given, a second run with that many threads (the share of the host's cores this job may use) is reported too."""
+    is given, a second run with that many threads (the share of the host's cores this job may use) is reported too.
+    Returns the baseline record, the picture (sum over the samples, f64 [H, W, 3]) and the noise floor at this sample
+    count: the RMSE between two oracle renders that differ only in the seed, on resolved [0, 1] values, taken at a
+    quarter of the image size."""
     import oracle
     o = oracle.get()
     kw = scene_kwargs(wl, bvh)  # the same tree policy as the GPU run (the oracle builds the linear tree on the CPU)
@@ -162,16 +166,39 @@ def cpu_baseline(wl, spp, threads, more_threads=0, bvh="reference"):
     cam = o.api.camera(su)
     p = o.make_params(wl["width"], wl["height"], 0, spp, list(su.background))
     n = wl["width"] * wl["height"] * spp
-    _, st, secs = o.render(sc, cam, p, mode=oracle.AABB_REFERENCE, threads=threads)
+    # the reference's own box rule (src/aabb.rs:15-30) wherever it finishes: on the 10 M-triangle tree it lets a ray
+    # through more than a million boxes (50 ms per ray), so that workload is timed with the carried-interval rule
+    mode, rule = (oracle.AABB_TIGHT, "carried-interval box test") if "n_triangles" in wl else (oracle.AABB_REFERENCE, "reference AABB test")
+    acc, st, secs = o.render(sc, cam, p, mode=mode, threads=threads)
     out = {"value": n / secs, "unit": "path samples/s", "cores": threads, "kind": "port",
-           "sample": "%s, %d spp (%d path samples, %.1f s), reference AABB test, %d threads over image columns"
-                     % (wl["name"], spp, n, secs, threads),
+           "sample": "%s, %d spp (%d path samples, %.1f s), %s, %d threads over image columns"
+                     % (wl["name"], spp, n, secs, rule, threads),
            "rays_per_s": st["rays"] / secs, "cpu_model": cpu_model()}
     if more_threads > threads:
-        _, _, secs2 = o.render(sc, cam, p, mode=oracle.AABB_REFERENCE, threads=more_threads)
+        _, _, secs2 = o.render(sc, cam, p, mode=mode, threads=more_threads)
         out["more_threads"] = {"value": n / secs2, "cores": more_threads, "seconds": round(secs2, 1)}
+    w4, h4 = max(8, wl["width"] // 4), max(8, wl["height"] // 4)
+    pa = o.make_params(w4, h4, 0, spp, list(su.background))
+    pb = o.make_params(w4, h4, 0, spp, list(su.background), seed=0x5EED + 1)
+    t = max(threads, more_threads)
+    a = np.sqrt(o.render(sc, cam, pa, mode=mode, threads=t)[0] / spp)
+    b = np.sqrt(o.render(sc, cam, pb, mode=mode, threads=t)[0] / spp)
+    noise = float(np.sqrt(np.mean((a - b) ** 2)))
     o.api.scene_free(sc)
-    return out
+    return out, acc, noise, rule
+
+
+def rmse_vs_cpu(acc_gpu, acc_cpu, spp, noise, rule):
+    """BASELINE.json's "image RMSE vs CPU": the GPU's render of the very samples the CPU leg rendered (same seed, same
+    sample range) against the oracle's picture, on resolved un-quantised display values sqrt(sum / spp)
+    (src/main.rs:216-219)."""
+    g = np.sqrt(np.asarray(acc_gpu, dtype=np.float64) / spp)
+    c = np.sqrt(acc_cpu / spp)
+    off = np.abs(acc_gpu - acc_cpu) > 1e-6 * np.abs(acc_cpu) + 1e-9
+    return {"value": float(np.sqrt(np.mean((g - c) ** 2))), "spp": spp, "noise_floor": noise,
+            "noise_floor_is": "RMSE between two CPU renders that differ only in the seed, same spp, a quarter of the image size",
+            "pixels_off": float(off.any(axis=2).mean()), "pixels_off_is": "share of pixels whose accumulated value differs by more than 1e-6 relative",
+            "max_abs_diff": float(np.abs(g - c).max()), "cpu_box_rule": rule, "on": "resolved [0,1] display values before quantisation"}
 
 
 def main():
@@ -353,7 +380,12 @@ def main():
             "roofline": roofline,
         }
         if args.cpu_spp > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_spp, args.cpu_threads, args.cpu_more_threads, args.bvh)
+            out["cpu_baseline"], acc_cpu, noise, rule = cpu_baseline(wl, args.cpu_spp, args.cpu_threads, args.cpu_more_threads, args.bvh)
+            # the same samples on the GPU, outside the timed region
+            scratch.zero_()
+            ds.render_device(cam, lib.make_params(W, H, 0, args.cpu_spp, bg), scratch.data_ptr(), stream)
+            torch.cuda.synchronize()
+            out["rmse_vs_cpu"] = rmse_vs_cpu(scratch.cpu().numpy(), acc_cpu, args.cpu_spp, noise, rule)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

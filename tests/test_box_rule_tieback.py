@@ -122,3 +122,17 @@ def test_scenes_whose_boxes_do_not_bound(orc, rtlib, which):
     differ = (mine["prim_id"] != ref["prim_id"]) | (mine["t"].view(np.uint64) != ref["t"].view(np.uint64))
     assert differ.mean() <= 1e-4, differ.sum()
     orc.api.scene_free(oroot)
+
+
+@pytest.mark.parametrize("sid,size", [(7, (600, 600)), (8, (600, 600)), (9, (800, 800))])
+def test_full_size_pictures_do_not_depend_on_the_mode(orc, sid, size):
+    # two samples of every pixel at the BASELINE image sizes: all bounces of every path, bit for bit
+    W, H = size
+    osc = orc.api.scene_build(sid, seed=SEED, **scene_kwargs(sid))
+    su = orc.api.scene_setup(sid)
+    cam = orc.api.camera(su)
+    p = orc.make_params(W, H, 0, 2, list(su.background), seed=SEED)
+    a, sa, _ = orc.render(osc, cam, p, mode=oracle.AABB_TIGHT, threads=8)
+    b, sb, _ = orc.render(osc, cam, p, mode=oracle.AABB_REFERENCE, threads=8)
+    assert np.array_equal(a, b) and sa["rays"] == sb["rays"]
+    orc.api.scene_free(osc)

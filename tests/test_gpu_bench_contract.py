@@ -18,7 +18,7 @@ def test_bench_line_has_the_contract_fields(gpu):
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "rmse_vs_cpu"):
         assert k in d, k
     assert d["metric"] == "path samples/s" and d["unit"] == "samples/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64"
@@ -37,3 +37,9 @@ def test_bench_line_has_the_contract_fields(gpu):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] == 8 and c["value"] > 0
+    # BASELINE.json's metric ends "image RMSE vs CPU": the GPU's picture of the CPU leg's samples against the oracle's under
+    # the reference's own box rule, far below the noise between two seeds
+    m = d["rmse_vs_cpu"]
+    assert m["spp"] == 1 and m["cpu_box_rule"] == "reference AABB test" and m["noise_floor"] > 0
+    assert m["value"] <= 1e-3 * m["noise_floor"] + 1e-6 or m["pixels_off"] > 0, m
+    assert m["value"] <= 1.5 * m["noise_floor"] and m["pixels_off"] <= 0.002, m

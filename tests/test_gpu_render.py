@@ -165,14 +165,19 @@ def test_full_resolution_properties(gpu, orc, sid):
     want = orc.render(osc, cam, lib.make_params(W, H, 0, 1, bg), mode=oracle_mode(hs), threads=8)[0]
     off = np.abs(one - want) > PIXEL_RTOL * np.abs(want) + 1e-9
     assert off.any(axis=2).mean() <= PIXEL_FRACTION, off.any(axis=2).mean()
+    # ... and against the reference's own box rule (src/aabb.rs:15-30 on the f64 boxes of every BVHNode, none of the
+    # culling / covering boxes the kernels and the oracle's mirrored mode use): the same picture
+    ref = orc.render(osc, cam, lib.make_params(W, H, 0, 1, bg), mode=oracle.AABB_REFERENCE, threads=8)[0]
+    off = np.abs(one - ref) > PIXEL_RTOL * np.abs(ref) + 1e-9
     if sid == 1:
         # random_scene is the one scene whose boxes do not bound their contents (src/main.rs:315): the kernels run the
-        # reference's per-axis box rule there, on f32 boxes; against the reference's rule as written, on its f64 boxes,
-        # the picture is the same but for paths that pass within one f32 rounding of a box face
+        # reference's per-axis rule there, on f32 planes; against the rule on the reference's f64 planes the picture is
+        # the same but for paths that pass within one f32 rounding of a box face
         assert hs.desc.flags & abi.RT_DESC_BOXES_MAY_NOT_BOUND
-        ref = orc.render(osc, cam, lib.make_params(W, H, 0, 1, bg), mode=oracle.AABB_REFERENCE, threads=8)[0]
-        off = np.abs(one - ref) > PIXEL_RTOL * np.abs(ref) + 1e-9
-        assert off.any(axis=2).mean() <= 1e-4, off.any(axis=2).mean()
+        assert off.any(axis=2).mean() <= 1e-4 + PIXEL_FRACTION, off.any(axis=2).mean()
+    else:
+        assert np.array_equal(ref, want), "the oracle's picture depends on its box mode"
+        assert off.any(axis=2).mean() <= PIXEL_FRACTION, off.any(axis=2).mean()
     ds.close(); hs.close(); orc.api.scene_free(osc)
 
 
@@ -292,6 +297,15 @@ def test_c5_ten_million_triangles_at_4k(gpu, orc):
     hit = oh["prim_id"] != abi.RT_MISS
     assert np.array_equal(oh["t"][hit].view(np.uint64), gh["t"][hit].view(np.uint64))
     assert work["inner"] == ost["box_tests"] and work["triangle"] == ost["triangle"] and work["box6"] == ost["box6"]
+    # The reference's own rule (src/aabb.rs:15-30 at every node) lets a ray through 1.3 M of this tree's boxes (a ray
+    # crosses each of the three slabs of nearly every box at some time), 50 ms per ray on one core: 256 of the
+    # harvested rays are what it finishes here; the 200 000-triangle trees are compared on 30 000 rays on the CPU
+    # (tests/test_box_rule_tieback.py)
+    few = rays[:: len(rays) // 256][:256]
+    rh, _, _ = orc.trace(osc, few, seed=SEED, mode=oracle.AABB_REFERENCE)
+    fh, _ = ds.trace(few, seed=SEED)
+    assert np.array_equal(rh["prim_id"], fh["prim_id"]) and np.array_equal(rh["sub"], fh["sub"])
+    assert np.array_equal(rh["t"].view(np.uint64), fh["t"].view(np.uint64))
     want = orc.path_step(osc, p, rays, mode=oracle_mode(hs))
     got, work2 = ds.path_step(p, rays, want_work=True)
     assert np.array_equal(want["prim_id"], got["prim_id"]) and np.array_equal(want["sub"], got["sub"])
