@@ -443,6 +443,11 @@ struct Hittable {  // :43-46
     // computed from the objects themselves (false: not known, behind a Translate / RotateY).
     virtual void motion_hull(double& /*lo*/, double& /*hi*/) const {}
     virtual bool bounds_over(double t0, double t1, AABB& out) const { return bounding_box(t0, t1, out); }
+    // Does the box this object presents to a tree built over an interval that covers its motion hull hold everything
+    // below it? Not when a tree below (or a RotateY, whose box is taken over (0, 1), :321) was built over an interval the
+    // motion of its own content reaches out of: a BVHNode's box is the union of its children's stored boxes
+    // (src/bvh.rs:80-88, :113-116), so every box above a box that does not hold does not hold either.
+    virtual bool holds_content() const { return true; }
 };
 using HitPtr = std::shared_ptr<Hittable>;
 
@@ -455,8 +460,12 @@ struct CullBox {
     mutable bool has = false;
     void adopt(const Hittable& self, double t0, double t1, bool primitive = false) const {
         AABB b;
-        // a wrapper: not around a single primitive; a primitive (a box of six sides that is a leaf of a tree): always
-        has = (primitive || !self.unwrap().one_entry()) && self.bounding_box(t0, t1, b);
+        // a wrapper: not around a single primitive, and only around content that does not move and whose own boxes hold
+        // it (the box is one the reference never tests: it may only cull what no ray of any time can hit); a primitive
+        // (a box of six sides that is a leaf of a tree): always
+        double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+        self.motion_hull(lo, hi);
+        has = (primitive || (!self.unwrap().one_entry() && !(lo <= hi) && self.holds_content())) && self.bounding_box(t0, t1, b);
         if (!has) return;
         // padded (2^-20 of the box's size and position) before it is rounded outward, so that no face of the object
         // coincides with a face of the box: a hit on such a face at exactly the running closest t would otherwise be
@@ -550,6 +559,10 @@ struct HittableList : Hittable {  // :124-185
         return true;
     }
     void motion_hull(double& lo, double& hi) const override { for (const auto& o : objects) o->motion_hull(lo, hi); }
+    bool holds_content() const override {
+        for (const auto& o : objects) if (!o->holds_content()) return false;
+        return true;
+    }
     bool bounds_over(double t0, double t1, AABB& out) const override {
         if (objects.empty()) return false;
         AABB temp;
@@ -627,6 +640,7 @@ struct Translate : Hittable {  // :262-304
     CullBox cull;
     const Hittable& unwrap() const override { return ptr->unwrap(); }
     void motion_hull(double& lo, double& hi) const override { ptr->motion_hull(lo, hi); }
+    bool holds_content() const override { return ptr->holds_content(); }
     bool bounds_over(double, double, AABB&) const override { return false; }
     void adopted_by_bvh(double t0, double t1, bool) const override { cull.adopt(*this, t0, t1); }
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :277-292
@@ -678,6 +692,11 @@ struct RotateY : Hittable {  // :306-392
     CullBox cull;
     const Hittable& unwrap() const override { return ptr->unwrap(); }
     void motion_hull(double& lo, double& hi) const override { ptr->motion_hull(lo, hi); }
+    bool holds_content() const override {
+        double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+        ptr->motion_hull(lo, hi);
+        return ptr->holds_content() && (!(lo <= hi) || (lo >= 0.0 && hi <= 1.0));
+    }
     bool bounds_over(double, double, AABB&) const override { return false; }
     void adopted_by_bvh(double t0, double t1, bool) const override { cull.adopt(*this, t0, t1); }
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :354-387
@@ -958,6 +977,7 @@ struct ConstantMedium : Hittable {  // :10-94
         return boundary->bounding_box(t0, t1, output_box);
     }
     void motion_hull(double& lo, double& hi) const override { boundary->motion_hull(lo, hi); }
+    bool holds_content() const override { return boundary->holds_content(); }
     bool bounds_over(double t0, double t1, AABB& out) const override { return boundary->bounds_over(t0, t1, out); }
 };
 
@@ -967,7 +987,8 @@ struct BVHNode : Hittable {  // :10-15
     AABB _box;
     FBox fbox;
     // Not in the reference; what the product's flattener does in scenes whose boxes may not bound their contents
-    // (AABB_PER_AXIS_F32). `holds`: every moving sphere below moves within the interval the node was built over, so the
+    // (AABB_PER_AXIS_F32). `holds`: every moving sphere below moves within the interval the node was built over and
+    // every tree / wrapper below holds its own content (holds_content), so the
     // box holds its content and is tested with the carried interval. Otherwise the box is tested with the reference's
     // per-axis rule, behind a covering box over the whole motion of what is below (carried interval, a box test of its
     // own): a ray that misses the covering box cannot hit anything below. Both only for rays whose time lies within the
@@ -975,6 +996,14 @@ struct BVHNode : Hittable {  // :10-15
     // extrapolates (src/hittable.rs:208-211) and no box built over the motion holds; such a ray gets the reference's
     // per-axis test on every node and passes every covering box.
     bool holds = false, has_cover = false;
+    bool content_held = false;  // what a tree above sees (a linear tree is walked without marks: holds stays false there)
+    bool holds_content() const override { return content_held; }
+    bool interval_covers_motion(double time0, double time1, double& lo, double& hi) const {
+        lo = std::numeric_limits<double>::infinity(); hi = -lo;
+        motion_hull(lo, hi);
+        // the flattener keeps the node's interval as f32, rounded inward
+        return !(lo <= hi) || (lo >= (double)f32_up(time0) && hi <= (double)f32_down(time1));
+    }
     FBox cover;
     // A node whose box contains the world's box (the root, and in final_scene the two nodes above the fog's sphere of
     // radius 5000) is passed by every ray that starts inside the world; the flattener gives such a node no entry, and
@@ -994,10 +1023,9 @@ struct BVHNode : Hittable {  // :10-15
     }
     // after left, right and _box are set by BVHNode::new over (time0, time1)
     void find_cover(double time0, double time1) {
-        double lo = std::numeric_limits<double>::infinity(), hi = -lo;
-        motion_hull(lo, hi);
-        // the flattener keeps the node's interval as f32, rounded inward
-        holds = !(lo <= hi) || (lo >= (double)f32_up(time0) && hi <= (double)f32_down(time1));
+        double lo, hi;
+        holds = interval_covers_motion(time0, time1, lo, hi) && left->holds_content() && (right.get() == left.get() || right->holds_content());
+        content_held = holds;
         AABB all;
         has_cover = !holds && bounds_over(lo, hi, all);
         if (!has_cover) return;
@@ -1160,8 +1188,11 @@ inline std::shared_ptr<BVHNode> lbvh_from_list(const std::vector<HitPtr>& object
     for (const HitPtr& o : objects) o->adopted_by_bvh(time0, time1, n_box6 >= K_MANY_BOXES);
     const std::vector<RtNode> tokens = orc_lbvh::build_tokens(boxes.data(), objects.size());
     size_t at = 0;
-    HitPtr root = lbvh_subtree(tokens, at, objects, time0, time1);
-    return std::static_pointer_cast<BVHNode>(root);
+    std::shared_ptr<BVHNode> root = std::static_pointer_cast<BVHNode>(lbvh_subtree(tokens, at, objects, time0, time1));
+    double lo, hi;
+    root->content_held = root->interval_covers_motion(time0, time1, lo, hi);
+    for (const HitPtr& o : objects) root->content_held = root->content_held && o->holds_content();
+    return root;
 }
 
 inline std::shared_ptr<BVHNode> BVHNode_new(HittableList& list, double time0, double time1) {  // :94-97

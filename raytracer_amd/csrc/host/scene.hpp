@@ -340,6 +340,12 @@ struct Hittable {
     // bounding_box it does not stop at a BVHNode's stored box (which holds its content over the interval the node was
     // built with only). false: not known (behind a Translate / RotateY).
     virtual bool bounds_over(double t0, double t1, AABB& out) const { return bounding_box(t0, t1, out); }
+    // Does the box this object presents to a tree built over an interval that covers its motion hull hold everything
+    // below it? Not when a tree (or a RotateY, whose box is taken over (0, 1) at construction, src/hittable.rs:321) below
+    // was built over an interval that the motion of its own content reaches out of: the box of a BVHNode is the union of
+    // its children's stored boxes (src/bvh.rs:80-88, :113-116), so a box that does not hold makes every box above it
+    // one that does not hold either, whatever interval those were built over.
+    virtual bool holds_content() const { return true; }
 
 protected:
     // Where this object's row went in the flattening under way, so that an object reached twice (shared Arc in the
@@ -370,7 +376,13 @@ struct CullBox {
     mutable bool has = false;
     // Not around a single primitive: that is tested in one step inside its wrappers, without entering and leaving
     // them, and a box in front of it only adds a step (measured on the Cornell box: 15 % slower with one).
-    void adopt(const Hittable& self, double t0, double t1) const { has = !self.unwrap().one_entry() && self.bounding_box(t0, t1, box); }
+    // Only around content that does not move and whose own boxes hold it: the box the wrapper presented to BVHNode::new
+    // is a box the reference never tests, so it may only cull what cannot be hit, for rays of every time.
+    void adopt(const Hittable& self, double t0, double t1) const {
+        double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+        self.motion_hull(lo, hi);
+        has = !self.unwrap().one_entry() && !(lo <= hi) && self.holds_content() && self.bounding_box(t0, t1, box);
+    }
     void adopt_primitive(const Hittable& self, double t0, double t1) const { has = self.bounding_box(t0, t1, box); }
     // the box entry in front of the wrapper's entries; returns its position or NONE
     uint32_t open(Flat& f) const {
@@ -550,6 +562,10 @@ struct HittableList : Hittable {  // src/hittable.rs:124-185
         return true;
     }
     void motion_hull(double& lo, double& hi) const override { for (const auto& o : objects) o->motion_hull(lo, hi); }
+    bool holds_content() const override {
+        for (const auto& o : objects) if (!o->holds_content()) return false;
+        return true;
+    }
     bool bounds_over(double t0, double t1, AABB& out) const override {
         if (objects.empty()) return false;
         AABB temp;
@@ -596,6 +612,7 @@ struct Translate : Hittable {  // src/hittable.rs:262-304
     CullBox cull;
     const Hittable& unwrap() const override { return ptr->unwrap(); }
     void motion_hull(double& lo, double& hi) const override { ptr->motion_hull(lo, hi); }
+    bool holds_content() const override { return ptr->holds_content(); }
     bool bounds_over(double, double, AABB&) const override { return false; }
     void adopted_by_bvh(double t0, double t1, bool) const override { cull.adopt(*this, t0, t1); }
     void flatten(Flat& f) const override {
@@ -640,6 +657,11 @@ struct RotateY : Hittable {  // src/hittable.rs:306-392
     CullBox cull;
     const Hittable& unwrap() const override { return ptr->unwrap(); }
     void motion_hull(double& lo, double& hi) const override { ptr->motion_hull(lo, hi); }
+    bool holds_content() const override {  // the box is taken over (0, 1) whatever tree the wrapper ends up in (:321)
+        double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+        ptr->motion_hull(lo, hi);
+        return ptr->holds_content() && (!(lo <= hi) || (lo >= 0.0 && hi <= 1.0));
+    }
     bool bounds_over(double, double, AABB&) const override { return false; }
     void adopted_by_bvh(double t0, double t1, bool) const override { cull.adopt(*this, t0, t1); }
     void flatten(Flat& f) const override {
@@ -664,6 +686,7 @@ struct ConstantMedium : Hittable {  // src/constant_medium.rs:10-31, 91-93
           id(ctx().next_prim++), rng_id(ctx().next_medium++) {}
     bool bounding_box(double t0, double t1, AABB& out) const override { return boundary->bounding_box(t0, t1, out); }
     void motion_hull(double& lo, double& hi) const override { boundary->motion_hull(lo, hi); }
+    bool holds_content() const override { return boundary->holds_content(); }
     bool bounds_over(double t0, double t1, AABB& out) const override { return boundary->bounds_over(t0, t1, out); }
     void flatten(Flat& f) const override {
         if (f.in_medium) throw std::invalid_argument("a ConstantMedium inside the boundary of another is not supported");
@@ -723,13 +746,22 @@ struct BVHNode : Hittable {  // src/bvh.rs:10-15
         return true;
     }
     // Does the stored box hold everything below for every ray time the moving spheres below are defined for? It was
-    // built over (time0, time1) (src/bvh.rs:83-88); a MovingSphere below whose motion interval reaches outside sticks
-    // out of it (the reference's random_scene: tree over (0, 0.1), spheres moving over (0, 1), src/main.rs:315).
+    // built over (time0, time1) (src/bvh.rs:83-88) as the union of what its children presented: a MovingSphere below
+    // whose motion interval reaches outside sticks out of it (the reference's random_scene: tree over (0, 0.1), spheres
+    // moving over (0, 1), src/main.rs:315), and so does the content of a child whose own box does not hold (a nested
+    // tree built over a shorter interval), whatever this node's interval.
+    virtual bool children_hold() const { return left->holds_content() && (right.get() == left.get() || right->holds_content()); }
+    mutable bool covered_known = false, covered_value = false;
     bool covered() const {
-        double lo = std::numeric_limits<double>::infinity(), hi = -lo;
-        motion_hull(lo, hi);
-        return !(lo <= hi) || (lo >= (double)time0 && hi <= (double)time1);
+        if (!covered_known) {
+            double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+            motion_hull(lo, hi);
+            covered_value = (!(lo <= hi) || (lo >= (double)time0 && hi <= (double)time1)) && children_hold();
+            covered_known = true;
+        }
+        return covered_value;
     }
+    bool holds_content() const override { return covered(); }
     void flatten(Flat& f) const override {
         CoverScope cover(f, time0, time1);
         // A box that holds its content is tested with the carried interval (RT_INNER_CARRIED), also in a scene where
@@ -918,6 +950,10 @@ struct DeviceBvh : BVHNode {  // left / right stay empty: the tree is made on th
     double t0 = 0.0, t1 = 0.0;
     mutable double ms_device = 0.0;
     void motion_hull(double& lo, double& hi) const override { for (const auto& o : objects) o->motion_hull(lo, hi); }
+    bool children_hold() const override {
+        for (const auto& o : objects) if (!o->holds_content()) return false;
+        return true;
+    }
     bool bounds_over(double a, double b, AABB& out) const override {
         AABB temp;
         for (size_t i = 0; i < objects.size(); ++i) {

@@ -108,3 +108,39 @@ def nested_cover_scene_pair(rng, rtlib, orc, n_obj=90, oracle_only=False):
         loose = [ball(k, 0.2, 0.7) if k % 2 else b.triangle(cs[k] + [0.8, 0, 0.1], cs[k] + [0, 0.8, -0.2], cs[k], m) for k in range(60, 90)]
         roots.append(b.finish(b.bvh(b.list([inner, wrapped, device] + loose), 0.0, 0.1)))
     return roots
+
+
+def nested_interval_scene_pair(rng, rtlib, orc, n_obj=60):
+    """Trees nested the other way round: an OUTER tree built over the whole motion (0, 1) around an inner tree built over
+    (0, 0.1) whose spheres move over (0, 1). The inner boxes do not hold their spheres, and because a node's box is the
+    union of its children's stored boxes (src/bvh.rs:80-88, :113-116) neither do the outer ones, although the outer
+    interval covers the motion. Also a Translate(RotateY(..)) around such an inner tree as a leaf of the outer tree
+    (the box it presents to BVHNode::new does not hold its content either), and a wrapper whose content moves over
+    (0, 2) in a tree over (0, 1)."""
+    cs = rng.uniform(-5, 5, (n_obj, 3))
+    mv = rng.uniform(-4.0, 4.0, (n_obj, 3))
+    roots = []
+    for api in (rtlib.host, orc.api):
+        b = api.builder(seed=31)
+        m = b.lambertian([0.5, 0.5, 0.5])
+
+        def ball(k, t0=0.0, t1=1.0):
+            return b.moving_sphere(cs[k], cs[k] + mv[k], t0, t1, 0.35, m)
+        inner = b.bvh(b.list([ball(k) for k in range(0, 20)]), 0.0, 0.1)
+        wrapped = b.translate(b.rotate_y(b.bvh(b.list([ball(k) for k in range(20, 30)]), 0.0, 0.1), 25.0), [0.5, -0.25, 1.0])
+        late = b.translate(b.list([ball(k, 0.0, 2.0) for k in range(30, 34)]), [0.25, 0.5, -1.0])
+        static = [b.sphere(cs[k], 0.3, m) if k % 2 else b.triangle(cs[k] + [0.8, 0, 0.1], cs[k] + [0, 0.8, -0.2], cs[k], m)
+                  for k in range(34, n_obj)]
+        roots.append(b.finish(b.bvh(b.list([inner, wrapped, late] + static), 0.0, 1.0)))
+    return roots
+
+
+def aimed_rays(rng, n, radius=14.0, extent=5.0):
+    """Rays from a sphere around the scene towards points inside it, of all times, with the render path's t range."""
+    rays = random_rays(rng, n)
+    org = rng.normal(size=(n, 3))
+    org *= radius / np.linalg.norm(org, axis=1)[:, None]
+    rays["o"] = org
+    rays["d"] = rng.uniform(-extent, extent, (n, 3)) - org
+    rays["tmin"], rays["tmax"] = 1e-4, np.inf
+    return rays

@@ -13,7 +13,7 @@ import pytest
 import oracle
 from conftest import CONFIG_SCENES, SEED, oracle_mode, scene_kwargs
 from raytracer_amd import abi, lib
-from scenegen import clipping_scene_pair, nested_cover_scene_pair, random_rays, random_scene_pair
+from scenegen import aimed_rays, clipping_scene_pair, nested_cover_scene_pair, nested_interval_scene_pair, random_rays, random_scene_pair
 
 
 def same_hits(a, b, what):
@@ -136,3 +136,33 @@ def test_full_size_pictures_do_not_depend_on_the_mode(orc, sid, size):
     b, sb, _ = orc.render(osc, cam, p, mode=oracle.AABB_REFERENCE, threads=8)
     assert np.array_equal(a, b) and sa["rays"] == sb["rays"]
     orc.api.scene_free(osc)
+
+
+def test_outer_tree_over_the_motion_around_an_inner_tree_that_is_not(orc, rtlib):
+    # A node's box is the union of its children's STORED boxes (src/bvh.rs:80-88, :113-116): an outer tree built over the
+    # whole motion (0, 1) around an inner tree built over (0, 0.1) does not hold the inner tree's spheres either, although
+    # its own interval covers their motion. Such outer nodes must keep the reference's per-axis test (behind a covering
+    # box), and a Translate / RotateY around moving content gets no culling box: the box it presented to BVHNode::new is
+    # one the reference never tests.
+    rng = np.random.default_rng(7)
+    hroot, oroot = nested_interval_scene_pair(rng, rtlib, orc)
+    hs = lib.HostScene(rtlib, hroot)
+    assert hs.desc.flags & abi.RT_DESC_BOXES_MAY_NOT_BOUND
+    nodes = hs.table("nodes")
+    kind, mark = nodes["meta"] & 15, nodes["meta"] >> 4
+    boxes = np.flatnonzero(kind == abi.RT_N_INNER)
+    assert mark[boxes[0]] in (0, abi.RT_INNER_COVER)          # the world's root does not hold its content
+    assert {0, abi.RT_INNER_CARRIED, abi.RT_INNER_COVER} <= set(mark[boxes].tolist())
+    # box entries = the nodes of the three trees (src/bvh.rs:17-91: one node per span of 1 or 2, else one plus the halves)
+    # plus the covering boxes, and nothing else: no culling box in front of the two wrappers
+    def n_nodes(n):
+        return 1 if n <= 2 else 1 + n_nodes(n // 2) + n_nodes(n - n // 2)
+    assert len(boxes) == n_nodes(29) + n_nodes(20) + n_nodes(10) + int((mark[boxes] == abi.RT_INNER_COVER).sum())
+    rays = np.concatenate([aimed_rays(rng, 60000), random_rays(rng, 20000)])
+    mine, _, st = orc.trace(oroot, rays, seed=5, mode=oracle.AABB_PER_AXIS_F32)
+    ref, _, rst = orc.trace(oroot, rays, seed=5, mode=oracle.AABB_REFERENCE)
+    assert (ref["prim_id"] != abi.RT_MISS).sum() > 8000
+    differ = (mine["prim_id"] != ref["prim_id"]) | (mine["t"].view(np.uint64) != ref["t"].view(np.uint64))
+    assert differ.sum() <= 2, differ.sum()  # (12 of the first 60 000 when the outer nodes were marked as holding)
+    hs.close()
+    orc.api.scene_free(oroot)

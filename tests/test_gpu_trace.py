@@ -10,7 +10,7 @@ import pytest
 import oracle
 from conftest import CONFIG_SCENES, SCENE_OPTS, SEED, load_golden, scene_kwargs, ulp_diff, oracle_mode
 from raytracer_amd import abi, lib
-from scenegen import clipping_scene_pair, nested_cover_scene_pair, random_rays, random_scene_pair
+from scenegen import aimed_rays, clipping_scene_pair, nested_cover_scene_pair, nested_interval_scene_pair, random_rays, random_scene_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -230,6 +230,25 @@ def test_covering_boxes_in_nested_trees(gpu, orc):
     ds.close()
     hs.close()
     orc.api.scene_free(roots[1])
+
+
+def test_outer_tree_over_the_motion_around_an_inner_tree_that_is_not(gpu, orc):
+    # an outer tree over (0, 1) around an inner tree over (0, 0.1) whose spheres move over (0, 1), wrappers around moving
+    # content: no box above the inner tree holds its content (see tests/test_box_rule_tieback.py for the reference's rule)
+    rng = np.random.default_rng(7)
+    hroot, oroot = nested_interval_scene_pair(rng, gpu, orc)
+    hs = lib.HostScene(gpu, hroot)
+    ds = lib.DeviceScene(hs)
+    rays = np.concatenate([aimed_rays(rng, 60000), random_rays(rng, 20000)])
+    oh, _, ost = orc.trace(oroot, rays, seed=5, mode=oracle.AABB_PER_AXIS_F32)
+    gh, work = ds.trace_work(rays, seed=5)
+    d = compare_hits(oh, gh, "nested intervals")
+    assert d.max(initial=0) == 0 and work["inner"] == ost["box_tests"] and work["msphere"] == ost["msphere"]
+    ref, _, _ = orc.trace(oroot, rays, seed=5, mode=oracle.AABB_REFERENCE)
+    assert ((ref["prim_id"] != gh["prim_id"]) | (ref["t"].view(np.uint64) != gh["t"].view(np.uint64))).sum() <= 2
+    ds.close()
+    hs.close()
+    orc.api.scene_free(oroot)
 
 
 def test_edge_cases(gpu, orc):
