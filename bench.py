@@ -92,26 +92,31 @@ def profile_key(workload, bvh, wl=None):
     return key
 
 
-def measured_traffic(workload, spp):
-    """HBM bytes per extend launch from the committed rocprofv3 counter passes (profiles/hbm_traffic.json), or
-    None when there is no measurement for this workload, tree policy and batch size: counters cannot be read from
-    inside a run."""
+def measured_traffic(workload, spp, field="bytes_per_launch"):
+    """HBM bytes per extend launch (or, for key "<workload>/shade", per step of shade launches) from the committed
+    rocprofv3 counter passes (profiles/hbm_traffic.json), or None when there is no measurement for this workload, tree
+    policy and batch size, or when the kernels have changed since it was taken (the record carries a hash of the kernel
+    sources): counters cannot be read from inside a run."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if not os.path.exists(path):
         return None
     t = json.load(open(path)).get(workload)
-    if not t or t.get("spp_per_step") != spp:
+    if not t or t.get("spp_per_step") != spp or t.get("kernel_sources") != lib.kernel_source_hash():
         return None
-    return t["bytes_per_launch"]
+    return t[field]
 
 
 def measured_valu(workload):
-    """What the committed SQ counter passes say about the closest-hit kernel (profiles/valu_issue.json): share of
-    issue cycles with a vector instruction, active-lane fraction, f64 lane-operations per second; None if absent."""
+    """What the committed SQ counter passes say about a kernel (profiles/valu_issue.json): share of issue cycles with a
+    vector instruction, active-lane fraction, f64 lane-operations per second; None if absent or taken with other
+    kernel sources than the current ones."""
     path = os.path.join(ROOT, "profiles", "valu_issue.json")
     if not os.path.exists(path):
         return None
-    return json.load(open(path)).get(workload)
+    v = json.load(open(path)).get(workload)
+    if not v or v.get("kernel_sources") != lib.kernel_source_hash():
+        return None
+    return v
 
 
 def algorithmic_flops(work):
@@ -367,6 +372,25 @@ def main():
                     "ms_extend_per_step": ms_extend / args.steps, "ms_shade_per_step": ms_shade / args.steps,
                     "avg_launch_ms": ms_extend / launches, "launches": launches,
                     "tables_in_lds": in_lds, "table_bytes": table_bytes}
+        # The second kernel of a bounce. Algorithmic bytes of the shade launches of one step: every ray's 96-byte record
+        # and 16-byte hit slot in, a 96-byte record out per ray that goes on (every ray after the camera rays is such a
+        # survivor), and the three 8-byte radiance columns read and written back for a path that gathers light.
+        own_steps = max(1, args.steps)
+        rays_step = rays / own_steps
+        survivors_step = max(0.0, rays_step - own_samples / own_steps)
+        lit_step = work["lit_slots"] * (own_samples / own_steps) / max(1, wst.paths)
+        shade_bytes = 112.0 * rays_step + 96.0 * survivors_step + 48.0 * lit_step
+        secs_shade = ms_shade / own_steps * 1e-3
+        shade_key = profile_key(args.workload, args.bvh, wl) + "/shade"
+        shade_traffic = measured_traffic(shade_key, S, "bytes_per_step")
+        roofline["shade"] = {"kernel": "k_shade", "bound": "hbm", "algorithmic_bytes_per_step": shade_bytes,
+                             "bytes_per_ray": shade_bytes / max(1.0, rays_step),
+                             "counts_per_step": {"rays": rays_step, "survivors": survivors_step, "paths_that_gathered_light": lit_step},
+                             "achieved": shade_bytes / secs_shade / 1e9 if secs_shade > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": shade_bytes / secs_shade / 1e9 / HBM_PEAK_GBS if secs_shade > 0 else 0.0,
+                             "traffic": shade_traffic,
+                             "measured_hbm_frac": (shade_traffic / secs_shade / 1e9 / HBM_PEAK_GBS) if shade_traffic and secs_shade > 0 else None,
+                             "measured": measured_valu(shade_key)}
         out = {
             "metric": "path samples/s", "value": samples_total / elapsed, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

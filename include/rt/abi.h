@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u   /* 2: RtSceneDesc.flags (was padding) and the box markers in RtNode.meta are validated */
 #define RT_MISS 0xFFFFFFFFu
 #define RT_NONE 0xFFFFFFFFu
 
@@ -246,7 +246,9 @@ int rt_render_device(RtScene* scene, const RtCamera* cam, const RtRenderParams* 
                      RtRenderStats* stats);
 
 /* Instrumented rt_render_device: same image, and the traversal work of all extend launches of the call summed
- * into work[10] (layout as in rt_trace_work). Waits for completion. Used to derive algorithmic bytes per ray. */
+ * into work[0 .. 9] (layout as in rt_trace_work); work[10] = path slots that gathered light (whose radiance
+ * columns the shade launches read, added to and wrote back), work[11] = 0. 12 words. Waits for completion. Used
+ * to derive the algorithmic bytes of the closest-hit and shade launches. */
 int rt_render_work(RtScene* scene, const RtCamera* cam, const RtRenderParams* params, float* accum_rgb_dev, void* stream,
                    RtRenderStats* stats, uint64_t* work);
 
@@ -363,12 +365,15 @@ int rt_bvh_refit_device(RtNode* tokens_dev, uint64_t n, const double* boxes_dev,
 
 #define RT_BVH_NOALLOC_MAX_OBJECTS 65536u
 #define RT_BVH_NOALLOC_SCRATCH_BYTES (16u << 20)
-/* rt_bvh_build_device for callers that cannot allocate: code under HIP graph capture, tight per-frame rebuild
- * loops, harnesses that forbid hipMalloc. It has no counterpart in the reference. Same arguments and same tokens
- * as rt_bvh_build_device, but it allocates nothing, neither device nor host memory, and does not wait: the work
- * is enqueued on `stream` and the call returns. The scratch memory of the build (sort keys, tree links, range
- * unions) lives in a static device array of RT_BVH_NOALLOC_SCRATCH_BYTES that each GPU the library runs on holds
- * until the process ends; n is limited to RT_BVH_NOALLOC_MAX_OBJECTS (RT_E_INVALID with a message beyond it).
+/* rt_bvh_build_device for callers that cannot allocate: tight per-frame rebuild loops, serving loops, harnesses that
+ * forbid hipMalloc. It has no counterpart in the reference. Same arguments and same tokens as rt_bvh_build_device,
+ * but on the success path it allocates nothing, neither device nor host memory (a refused call builds its message
+ * in a std::string), and does not wait: the work is enqueued on `stream` and the call returns. The scratch memory of
+ * the build (sort keys, tree links, range unions) lives in a static device array of RT_BVH_NOALLOC_SCRATCH_BYTES that
+ * each GPU the library runs on holds until the process ends; n is limited to RT_BVH_NOALLOC_MAX_OBJECTS (RT_E_INVALID
+ * with a message beyond it). The first call on a device looks the array's address up (hipGetSymbolAddress, which may
+ * load the library's code on that device): make one call per device before entering a region that must not allocate.
+ * `stream` must belong to the current device (RT_E_INVALID otherwise): each GPU has its own array.
  * All calls on one GPU share that array: two calls whose work overlaps in time on one GPU (different streams,
  * different threads) race; order them on one stream or with events. */
 int rt_bvh_build_device_noalloc(const double* boxes_dev, uint64_t n, RtNode* tokens_dev, uint32_t* flag_dev, void* stream);

@@ -7,7 +7,7 @@ import numpy as np
 
 RT_MISS = 0xFFFFFFFF
 RT_NONE = 0xFFFFFFFF
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 RT_OK, RT_E_INVALID, RT_E_DEVICE, RT_E_NOMEM, RT_E_UNSUPPORTED = 0, -1, -2, -3, -4
 RT_N_INNER, RT_N_SPHERE, RT_N_MSPHERE, RT_N_RECT, RT_N_BOX6, RT_N_TRIANGLE, RT_N_XF_ENTER, RT_N_XF_EXIT, RT_N_MEDIUM = range(9)
 RT_INNER_CARRIED, RT_INNER_COVER = 1, 2  # markers of box entries (index field of meta)

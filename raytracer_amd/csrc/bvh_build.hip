@@ -637,9 +637,17 @@ constexpr int MAX_DEVICES = 64;
 std::mutex g_scratch_mutex;
 char* g_scratch_ptr[MAX_DEVICES] = {};  // device address of `scratch` on each GPU, looked up on first use
 
-int scratch_on_current_device(char** out) {
+// The scratch array of the device `stream` belongs to. Kernels enqueued on a stream run on the stream's device, so that
+// device's copy of the array is the one they must be given; a stream of another device than the current one is refused
+// (the launches below go to the current device).
+int scratch_for_stream(hipStream_t stream, char** out) {
     int dev = -1;
     BVH_TRY(hipGetDevice(&dev));
+    if (stream) {
+        int stream_dev = -1;
+        BVH_TRY(hipStreamGetDevice(stream, &stream_dev));
+        if (stream_dev != dev) return rt::set_error(RT_E_INVALID, "the stream belongs to another device than the current one");
+    }
     if (dev < 0 || dev >= MAX_DEVICES) return rt::set_error(RT_E_UNSUPPORTED, "device ordinal beyond the scratch table");
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
@@ -668,7 +676,7 @@ extern "C" int rt_bvh_build_device_noalloc(const double* boxes_dev, uint64_t n64
         return rt::set_error(RT_E_INVALID, "the build needs " + std::to_string(need) + " bytes of scratch memory, the static area holds " +
                                                std::to_string((size_t)RT_BVH_NOALLOC_SCRATCH_BYTES));
     char* base = nullptr;
-    if (int rc = scratch_on_current_device(&base)) return rc;
+    if (int rc = scratch_for_stream((hipStream_t)stream, &base)) return rc;
     // every array of the build is written in full before it is read, except the flag word, which enqueue_build clears;
     // what an earlier call left behind beyond this call's n is never read
     return enqueue_build(boxes_dev, n, tokens_dev, flag_dev, carve(base, n, sort_bytes), (hipStream_t)stream);

@@ -789,20 +789,27 @@ __global__ void __launch_bounds__(BLOCK) k_step_unpack_survivors(PathState P, ui
 }
 
 // ---- accumulate: sum the batch's samples of each pixel in sample order ---------------------------
-__global__ void __launch_bounds__(BLOCK) k_accumulate(RenderConst C, PathState P, float* __restrict__ accum) {
+// lit_out, when not null (instrumented renders only): receives the number of slots whose radiance columns hold light,
+// i.e. that the shade launches read, added to and wrote back (a path gathers light at most once: a miss and an emitter
+// both end it, src/color.rs:41-43, src/material.rs:167-178)
+__global__ void __launch_bounds__(BLOCK) k_accumulate(RenderConst C, PathState P, float* __restrict__ accum, unsigned long long* __restrict__ lit_out) {
     const uint32_t stride = gridDim.x * BLOCK;
     const uint32_t n_samples = C.n_slots / C.npix;
+    uint32_t lit = 0u;
     for (uint32_t pix = blockIdx.x * BLOCK + threadIdx.x; pix < C.npix; pix += stride) {
         double r = 0.0, g = 0.0, b = 0.0;
         for (uint32_t s = 0; s < n_samples; ++s) {
             const uint32_t slot = s * C.npix + pix;
-            r += P.lr[slot]; g += P.lg[slot]; b += P.lb[slot];
+            const double sr = P.lr[slot], sg = P.lg[slot], sb = P.lb[slot];
+            if (lit_out && (sr != 0.0 || sg != 0.0 || sb != 0.0)) ++lit;
+            r += sr; g += sg; b += sb;
         }
         float* a = accum + (size_t)pix * 3u;
         a[0] = (float)((double)a[0] + r);
         a[1] = (float)((double)a[1] + g);
         a[2] = (float)((double)a[2] + b);
     }
+    if (lit_out && lit) atomicAdd(lit_out, (unsigned long long)lit);
 }
 
 // ---- resolve (src/main.rs:212-225) -----------------------------------------------------------------

@@ -22,6 +22,7 @@ using rtd::RenderConst;
 constexpr uint64_t kDefaultSlotTarget = 640ull << 20;  // path slots per wavefront batch when the caller does not say (145 GiB)
 constexpr uint64_t kBytesPerSlot = 2 * sizeof(rtd::RayRec) + sizeof(rtd::HitSlot) + 3 * sizeof(double);
 constexpr int kWorkWords = 10;                      // entries + 9 kinds
+constexpr int kRenderWorkWords = 12;                // rt_render_work: the same + slots that gathered light + one spare word
 
 #define HIP_TRY(expr)                                                                                      \
     do {                                                                                                   \
@@ -36,7 +37,7 @@ struct Workspace {
     char* base = nullptr;  // one allocation: two record arrays, hit slots, three radiance columns
     PathState P{};
     uint32_t* counts = nullptr;              // [0], [1] queue lengths, [2] ray cursor of the extend launch, [3] cursor of rt_trace_*
-    unsigned long long* ray_total = nullptr; // [1] + work counters [kWorkWords]
+    unsigned long long* ray_total = nullptr; // [1] + work counters [kRenderWorkWords]
     std::vector<hipEvent_t> events;
 };
 
@@ -202,7 +203,7 @@ int ensure_workspace(RtScene* s, uint64_t n_slots) {
     Workspace& w = s->ws;
     if (!w.counts) {
         HIP_TRY(hipMalloc((void**)&w.counts, 4 * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&w.ray_total, (1 + kWorkWords) * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&w.ray_total, (1 + kRenderWorkWords) * sizeof(unsigned long long)));
     }
     if (w.cap_slots >= n_slots) return RT_OK;
     if (w.base) { HIP_TRY(hipFree(w.base)); w.base = nullptr; w.cap_slots = 0; }
@@ -312,7 +313,7 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         w.events.push_back(e);
     }
     size_t ev = 0;
-    HIP_TRY(hipMemsetAsync(w.ray_total, 0, (1 + kWorkWords) * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(w.ray_total, 0, (1 + kRenderWorkWords) * sizeof(unsigned long long), stream));
     HIP_TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), stream));
     if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
     for (uint32_t b = 0; b < n_batches; ++b) {
@@ -330,7 +331,8 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
             launch_shade(s, C, cur, bounce, stream);
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
         }
-        hipLaunchKernelGGL(rtd::k_accumulate, dim3(grid_for(s, npix)), dim3(rtd::BLOCK), 0, stream, C, w.P, accum_dev);
+        hipLaunchKernelGGL(rtd::k_accumulate, dim3(grid_for(s, npix)), dim3(rtd::BLOCK), 0, stream, C, w.P, accum_dev,
+                           work ? w.ray_total + 1 + kWorkWords : nullptr);
     }
     HIP_TRY(hipGetLastError());
     if (stats) {
@@ -354,9 +356,9 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     }
     if (work) {
         HIP_TRY(hipStreamSynchronize(stream));
-        unsigned long long tmp[kWorkWords];
+        unsigned long long tmp[kRenderWorkWords];
         HIP_TRY(hipMemcpy(tmp, w.ray_total + 1, sizeof tmp, hipMemcpyDeviceToHost));
-        for (int k = 0; k < kWorkWords; ++k) work[k] = tmp[k];
+        for (int k = 0; k < kRenderWorkWords; ++k) work[k] = tmp[k];
     }
     return RT_OK;
 }
@@ -736,7 +738,7 @@ int rt_path_step(RtScene* s, const RtRenderParams* p, int profile, const RtRay* 
     hipStream_t stream = nullptr;
     HIP_TRY(hipMemcpy(d_rays_v, rays, n * sizeof(RtRay), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_idx, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemsetAsync(w.ray_total, 0, (1 + kWorkWords) * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(w.ray_total, 0, (1 + kRenderWorkWords) * sizeof(unsigned long long), stream));
 
     RenderConst C{};
     C.seed = p->seed;

@@ -5,12 +5,15 @@
 // numbers of a path are keyed by (pixel, sample, bounce) the picture does not depend on the partition except for
 // the order of the f32 additions.
 //
-// One host thread and one stream per device. RCCL is loaded at run time (dlopen), so the library has no link-time
-// dependency on it and single-GPU users never touch it.
+// One host thread and one stream per device; the threads are started once per scene and wait for renders (a render
+// call hands each its share and waits for all), and the picture crosses PCIe through a pinned staging buffer of the
+// scene. RCCL is loaded at run time (dlopen), so the library has no link-time dependency on it and single-GPU users
+// never touch it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -84,6 +87,10 @@ struct Shard {
     float* accum = nullptr;
     size_t accum_floats = 0;
     void* comm = nullptr;
+    // the worker thread's report of the current render
+    int rc = RT_OK;
+    std::string err;
+    RtRenderStats stats{};
 };
 
 }  // namespace
@@ -91,7 +98,68 @@ struct Shard {
 struct RtShardedScene {
     std::vector<Shard> shards;
     bool have_comm = false;
+    // pinned host memory the picture is staged in on its way to and from device 0
+    float* pinned = nullptr;
+    size_t pinned_floats = 0;
+    // the worker threads (one per shard, started by rt_sharded_create) and the render they are working on
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    uint64_t generation = 0;       // bumped by every render call
+    uint32_t remaining = 0;        // workers that have not finished the current generation
+    bool quit = false;
+    const RtCamera* cam = nullptr;
+    const RtRenderParams* params = nullptr;
+    size_t floats = 0;
 };
+
+namespace {
+
+// What shard i does for one render: its accumulation buffer starts from the caller's picture (shard 0, staged in the
+// pinned buffer) or from zero, then its share of the samples is rendered into it.
+int shard_render(RtShardedScene* s, uint32_t i) {
+    Shard& sh = s->shards[i];
+    const size_t floats = s->floats;
+    const uint32_t world = (uint32_t)s->shards.size();
+    if (sh.accum_floats < floats) {
+        if (sh.accum) { HIP_TRY(hipFree(sh.accum)); sh.accum = nullptr; sh.accum_floats = 0; }
+        HIP_TRY(hipMalloc((void**)&sh.accum, floats * sizeof(float)));
+        sh.accum_floats = floats;
+    }
+    // the sum over devices must come out as caller's buffer + all samples: the first device starts from the caller's
+    // values, the others from zero
+    if (i == 0u) HIP_TRY(hipMemcpyAsync(sh.accum, s->pinned, floats * sizeof(float), hipMemcpyHostToDevice, sh.stream));
+    else HIP_TRY(hipMemsetAsync(sh.accum, 0, floats * sizeof(float), sh.stream));
+    RtRenderParams q = *s->params;
+    rt_shard_samples(s->params->sample_begin, s->params->sample_end, i, world, &q.sample_begin, &q.sample_end);
+    std::memset(&sh.stats, 0, sizeof sh.stats);
+    if (q.sample_end > q.sample_begin)
+        if (int rc = rt_render_device(sh.scene, s->cam, &q, sh.accum, sh.stream, &sh.stats)) return rc;
+    HIP_TRY(hipStreamSynchronize(sh.stream));
+    return RT_OK;
+}
+
+void worker_main(RtShardedScene* s, uint32_t i) {
+    (void)hipSetDevice(s->shards[i].device);  // once: the current device is a property of the thread
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lock(s->m);
+            s->cv_job.wait(lock, [&] { return s->quit || s->generation != seen; });
+            if (s->quit) return;
+            seen = s->generation;
+        }
+        Shard& sh = s->shards[i];
+        sh.rc = shard_render(s, i);
+        sh.err = sh.rc ? rt_last_error() : "";  // the message is thread-local: carry it to the caller's thread
+        {
+            std::lock_guard<std::mutex> lock(s->m);
+            if (--s->remaining == 0) s->cv_done.notify_all();
+        }
+    }
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -107,6 +175,13 @@ void rt_shard_samples(uint32_t sample_begin, uint32_t sample_end, uint32_t rank,
 
 void rt_sharded_destroy(RtShardedScene* s) {
     if (!s) return;
+    {
+        std::lock_guard<std::mutex> lock(s->m);
+        s->quit = true;
+    }
+    s->cv_job.notify_all();
+    for (auto& t : s->workers) t.join();
+    if (s->pinned) (void)hipHostFree(s->pinned);
     const Rccl* r = s->have_comm ? rccl() : nullptr;
     for (Shard& sh : s->shards) {
         if (sh.device < 0) continue;
@@ -170,6 +245,7 @@ int rt_sharded_create(const RtSceneDesc* desc, const int* devices, int n_devices
     const int rc = body();
     (void)hipSetDevice(before);
     if (rc) { rt_sharded_destroy(s); return rc; }
+    for (uint32_t i = 0; i < (uint32_t)devs.size(); ++i) s->workers.emplace_back(worker_main, s, i);
     *out = s;
     return RT_OK;
 }
@@ -181,40 +257,23 @@ int rt_sharded_render(RtShardedScene* s, const RtCamera* cam, const RtRenderPara
     const uint32_t world = (uint32_t)s->shards.size();
     int before = 0;
     (void)hipGetDevice(&before);
-    std::vector<int> rcs(world, RT_OK);
-    std::vector<std::string> errs(world);
-    std::vector<RtRenderStats> sts(world);
-    std::vector<std::thread> pool;
-    for (uint32_t i = 0; i < world; ++i) {
-        pool.emplace_back([&, i]() {
-            Shard& sh = s->shards[i];
-            auto run = [&]() -> int {
-                HIP_TRY(hipSetDevice(sh.device));
-                if (sh.accum_floats < floats) {
-                    if (sh.accum) { HIP_TRY(hipFree(sh.accum)); sh.accum = nullptr; sh.accum_floats = 0; }
-                    HIP_TRY(hipMalloc((void**)&sh.accum, floats * sizeof(float)));
-                    sh.accum_floats = floats;
-                }
-                // the sum over devices must come out as caller's buffer + all samples: the first device starts from
-                // the caller's values, the others from zero
-                if (i == 0u) HIP_TRY(hipMemcpyAsync(sh.accum, accum_rgb, floats * sizeof(float), hipMemcpyHostToDevice, sh.stream));
-                else HIP_TRY(hipMemsetAsync(sh.accum, 0, floats * sizeof(float), sh.stream));
-                RtRenderParams q = *p;
-                rt_shard_samples(p->sample_begin, p->sample_end, i, world, &q.sample_begin, &q.sample_end);
-                std::memset(&sts[i], 0, sizeof sts[i]);
-                if (q.sample_end > q.sample_begin)
-                    if (int rc = rt_render_device(sh.scene, cam, &q, sh.accum, sh.stream, &sts[i])) return rc;
-                HIP_TRY(hipStreamSynchronize(sh.stream));
-                return RT_OK;
-            };
-            rcs[i] = run();
-            if (rcs[i]) errs[i] = rt_last_error();  // the message is thread-local: carry it to the caller's thread
-        });
+    if (s->pinned_floats < floats) {
+        if (s->pinned) { HIP_TRY(hipHostFree(s->pinned)); s->pinned = nullptr; s->pinned_floats = 0; }
+        HIP_TRY(hipHostMalloc((void**)&s->pinned, floats * sizeof(float), hipHostMallocPortable));
+        s->pinned_floats = floats;
     }
-    for (auto& t : pool) t.join();
+    std::memcpy(s->pinned, accum_rgb, floats * sizeof(float));
+    {
+        std::unique_lock<std::mutex> lock(s->m);
+        s->cam = cam; s->params = p; s->floats = floats;
+        s->remaining = world;
+        ++s->generation;
+        s->cv_job.notify_all();
+        s->cv_done.wait(lock, [&] { return s->remaining == 0; });
+    }
     auto finish = [&]() -> int {
         for (uint32_t i = 0; i < world; ++i)
-            if (rcs[i]) return rt::set_error(rcs[i], "device " + std::to_string(s->shards[i].device) + ": " + errs[i]);
+            if (s->shards[i].rc) return rt::set_error(s->shards[i].rc, "device " + std::to_string(s->shards[i].device) + ": " + s->shards[i].err);
         if (s->have_comm) {
             const Rccl* r = rccl();
             if (int e = r->GroupStart()) return rccl_fail(r, "ncclGroupStart", e);
@@ -227,21 +286,24 @@ int rt_sharded_render(RtShardedScene* s, const RtCamera* cam, const RtRenderPara
             }
             if (int e = r->GroupEnd()) return rccl_fail(r, "ncclGroupEnd", e);
         }
+        // the sum lands in every device's buffer; device 0's goes back to the caller, behind the all-reduce on its stream
+        HIP_TRY(hipSetDevice(s->shards[0].device));
+        HIP_TRY(hipMemcpyAsync(s->pinned, s->shards[0].accum, floats * sizeof(float), hipMemcpyDeviceToHost, s->shards[0].stream));
         for (uint32_t i = 0; i < world; ++i) {
             HIP_TRY(hipSetDevice(s->shards[i].device));
             HIP_TRY(hipStreamSynchronize(s->shards[i].stream));
         }
-        HIP_TRY(hipSetDevice(s->shards[0].device));
-        HIP_TRY(hipMemcpy(accum_rgb, s->shards[0].accum, floats * sizeof(float), hipMemcpyDeviceToHost));
+        std::memcpy(accum_rgb, s->pinned, floats * sizeof(float));
         if (stats) {
             std::memset(stats, 0, sizeof *stats);
             for (uint32_t i = 0; i < world; ++i) {
-                stats->paths += sts[i].paths;
-                stats->rays += sts[i].rays;
-                stats->batches = std::max(stats->batches, sts[i].batches);
-                stats->ms_total = std::max(stats->ms_total, sts[i].ms_total);    // the devices run side by side
-                stats->ms_extend = std::max(stats->ms_extend, sts[i].ms_extend);
-                stats->ms_shade = std::max(stats->ms_shade, sts[i].ms_shade);
+                const RtRenderStats& st = s->shards[i].stats;
+                stats->paths += st.paths;
+                stats->rays += st.rays;
+                stats->batches = std::max(stats->batches, st.batches);
+                stats->ms_total = std::max(stats->ms_total, st.ms_total);    // the devices run side by side
+                stats->ms_extend = std::max(stats->ms_extend, st.ms_extend);
+                stats->ms_shade = std::max(stats->ms_shade, st.ms_shade);
             }
         }
         return RT_OK;

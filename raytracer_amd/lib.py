@@ -253,11 +253,24 @@ class DeviceScene:
     def render_work(self, cam, params, accum_ptr, stream=None):
         """rt_render_work: returns (stats, work dict) for an instrumented render into a device buffer."""
         st = abi.RtRenderStats()
-        work = (C.c_uint64 * 10)()
+        work = (C.c_uint64 * 12)()
         self.lib.check(self.lib.lib.rt_render_work(self.h, C.byref(cam), C.byref(params), C.c_void_p(accum_ptr),
                                                   C.c_void_p(stream or 0), C.byref(st), work))
         w = list(work)
-        return st, {"entries": w[0], **{abi.NODE_KINDS[k]: w[1 + k] for k in range(9)}}
+        return st, {"entries": w[0], **{abi.NODE_KINDS[k]: w[1 + k] for k in range(9)}, "lit_slots": w[10]}
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the sources of the device code, in a fixed order: identifies the kernels a
+    counter measurement under profiles/ was taken with."""
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    names = sorted(os.path.join("device", f) for f in os.listdir(os.path.join(csrc, "device")) if f.endswith(".h")) + ["rng.h", "rt_hip.hip"]
+    h = hashlib.sha256()
+    for name in names:
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 class ShardedScene:

@@ -54,7 +54,7 @@ const RT_N_XF_ENTER: u32 = 6;
 const RT_N_XF_EXIT: u32 = 7;
 const RT_N_MEDIUM: u32 = 8;
 const RT_NONE: u32 = 0xFFFF_FFFF;
-const RT_ABI_VERSION: u32 = 1;
+const RT_ABI_VERSION: u32 = 2;
 
 fn a3(v: &Vec3) -> [f64; 3] { [v.x, v.y, v.z] }
 fn key<T: ?Sized>(p: &T) -> usize { p as *const T as *const u8 as usize }

@@ -344,5 +344,36 @@ def test_sharded_render_through_the_c_abi(gpu, orc):
         lib.ShardedScene(hs, devices=[0, 0])
     with pytest.raises(lib.RtError):
         lib.ShardedScene(hs, devices=[gpu.device_count()])
+    # several renders on the same handle (the worker threads and the pinned staging buffer are kept between calls),
+    # also of another size
+    again, _ = one.render(cam, p)
+    assert np.array_equal(again, want)
+    p2 = lib.make_params(64, 48, 0, 5, bg)
+    assert np.array_equal(one.render(cam, p2)[0], ds.render(cam, p2)[0])
     sh.close(); one.close()
+    ds.close(); hs.close(); orc.api.scene_free(osc)
+
+
+def test_sharded_render_on_two_devices(gpu, orc):
+    # Needs two GPUs in one process: devices 0 and 1 each render their share of the samples (rt_shard_samples), the RCCL
+    # all-reduce over both sums them. Against rt_render on one device: the same samples, f32 additions in another order.
+    if gpu.device_count() < 2:
+        pytest.skip("one GPU: the two-device all-reduce has nothing to run on")
+    hs, ds, osc, su, cam = setup_pair(gpu, orc, 9)
+    W = H = 96
+    bg = list(su.background)
+    p = lib.make_params(W, H, 3, 12, bg)  # nine samples: shares of five and four
+    want, st0 = ds.render(cam, p)
+    sh = lib.ShardedScene(hs, devices=[0, 1])
+    assert sh.device_count() == 2
+    got, st = sh.render(cam, p, accum=np.full((H, W, 3), 0.25, dtype=np.float32))
+    assert st.paths == st0.paths and st.rays == st0.rays
+    assert np.allclose(got, want + 0.25, rtol=2e-6, atol=1e-6)
+    # the partition itself: each share rendered on its own on one device adds up to the same picture
+    parts = np.zeros_like(want)
+    for r in range(2):
+        lo, hi = lib.shard_samples(gpu, 3, 12, r, 2)
+        parts += ds.render(cam, lib.make_params(W, H, lo, hi, bg))[0]
+    assert np.allclose(got, parts + 0.25, rtol=2e-6, atol=1e-6)
+    sh.close()
     ds.close(); hs.close(); orc.api.scene_free(osc)

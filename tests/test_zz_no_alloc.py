@@ -64,6 +64,29 @@ def test_no_alloc_build_equals_the_allocating_build(gpu):
     assert flag == 1
 
 
+def test_no_alloc_build_leaves_device_memory_alone(gpu):
+    """What the entry point is named for: after one call on the device (which looks the scratch array's address up and may
+    load code), further calls change neither the device's free memory nor wait for the device."""
+    import torch
+    sizes = (40_000, 300, MAX_OBJECTS)
+    bufs = []
+    for k, n in enumerate(sizes):
+        b = torch.from_numpy(boxes_for(n, 20 + k)).cuda()
+        bufs.append((b, n, torch.zeros((2 * n - 1) * 32, dtype=torch.uint8, device="cuda")))
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    b, n, t = bufs[0]
+    gpu.check(gpu.lib.rt_bvh_build_device_noalloc(b.data_ptr(), n, t.data_ptr(), flag.data_ptr(), None))  # warm-up
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for b, n, t in bufs:
+        gpu.check(gpu.lib.rt_bvh_build_device_noalloc(b.data_ptr(), n, t.data_ptr(), flag.data_ptr(), None))
+        assert torch.cuda.mem_get_info()[0] == free0, n  # while the build may still be running
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    for (b, n, t), k in zip(bufs, range(len(sizes))):
+        assert t.cpu().numpy().tobytes() == gpu.bvh_build(boxes_for(n, 20 + k))[0].tobytes(), n
+
+
 def test_no_alloc_build_refuses_what_does_not_fit(gpu):
     import torch
     n = MAX_OBJECTS + 1

@@ -9,12 +9,18 @@ SPP: samples per step of the profiled run; SECONDS_PER_LAUNCH: the kernel's aver
 RAYS_PER_LAUNCH: give it for a scene whose tables live in HBM. FETCH_SIZE tallies the wide in-order reads of the ray
 records at half their bytes and scattered 32-byte entry reads at the 64 bytes they fetch (tools/fetch_calibrate.hip), so
 for a scene in LDS (reads = records only) FETCH_SIZE is doubled, and for a scene in HBM only the records' missing half,
-48 bytes per ray, is added."""
+48 bytes per ray, is added.
+Environment: SHADE_KERNEL (e.g. "rtd::k_shade<true, true>") and SHADE_SECONDS_PER_STEP also record the shade launches of
+one step under KEY + "/shade": the sorting variant gathers whole records through a permutation, which FETCH_SIZE tallies
+at 0.89 of the bytes (tools/fetch_calibrate.hip), the plain variant streams them in order (tallied at half).
+Every record carries a hash of the kernel sources it was measured with; bench.py ignores records of other sources."""
 import json
 import os
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from raytracer_amd.lib import kernel_source_hash  # noqa: E402
 
 
 def counters(path, kernel):
@@ -55,7 +61,22 @@ def main(key, tag, kernel, spp, secs, rays_per_launch=None):
               "bytes_per_launch": corrected, "bytes_per_launch_uncorrected": raw,
               "correction": how,
               "source": "profiles/%s_pmc_fetch.txt and profiles/%s_pmc_write.txt (rocprofv3 --pmc, separate passes)" % (tag, tag),
-              "spp_per_step": int(spp)}
+              "spp_per_step": int(spp), "kernel_sources": kernel_source_hash()}
+    shade = os.environ.get("SHADE_KERNEL")
+    if shade:
+        sf = counters(os.path.join(prof, tag + "_pmc_fetch.txt"), shade)
+        sw = counters(os.path.join(prof, tag + "_pmc_write.txt"), shade)
+        steps = sf["_dispatches"] / 50.0  # 50 launches per step (the timed step and the instrumented pass of bench.py)
+        sorting = shade.rstrip(">").split(",")[-1].strip() == "true"
+        factor = 1.0 / 0.89 if sorting else 2.0
+        t[key + "/shade"] = {"kernel": shade, "launches": sf["_dispatches"], "fetch_size_kib": sf["FETCH_SIZE"], "write_size_kib": sw["WRITE_SIZE"],
+                             "bytes_per_step": (factor * sf["FETCH_SIZE"] + sw["WRITE_SIZE"]) * 1024.0 / steps,
+                             "bytes_per_step_uncorrected": (sf["FETCH_SIZE"] + sw["WRITE_SIZE"]) * 1024.0 / steps,
+                             "correction": ("FETCH_SIZE / 0.89: the gather of 96-byte records within sorting windows is tallied at 0.89 of its bytes "
+                                            "(tools/fetch_calibrate.hip, profiles/r02_fetch_calibrate_*)" if sorting else
+                                            "FETCH_SIZE doubled: in-order reads of the records are tallied at half") + "; WRITE_SIZE as reported",
+                             "source": "profiles/%s_pmc_fetch.txt and profiles/%s_pmc_write.txt" % (tag, tag),
+                             "spp_per_step": int(spp), "kernel_sources": kernel_source_hash()}
     json.dump(t, open(path, "w"), indent=1)
     lanes = s["SQ_THREAD_CYCLES_VALU"] / (s["SQ_ACTIVE_INST_VALU"] * 64.0)
     lane_ops = s["SQ_INSTS_VALU"] * 64.0 * lanes / (s["_dispatches"] * float(secs))
@@ -66,7 +87,15 @@ def main(key, tag, kernel, spp, secs, rays_per_launch=None):
               "wave_cycles_waiting_on_memory_or_barrier": s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"],
               "lane_ops_per_s": lane_ops, "lane_op_peak_per_s": 39.3e12, "lane_op_frac": lane_ops / 39.3e12,
               "note": "lane_ops = SQ_INSTS_VALU x 64 x active-lane fraction / kernel time; peak = 256 CUs x 64 f64 lanes x 2.4 GHz (all vector instructions priced as f64)",
-              "source": "profiles/%s_pmc_issue.txt" % tag}
+              "source": "profiles/%s_pmc_issue.txt" % tag, "kernel_sources": kernel_source_hash()}
+    if shade:
+        ss = counters(os.path.join(prof, tag + "_pmc_issue.txt"), shade)
+        sl = ss["SQ_THREAD_CYCLES_VALU"] / (ss["SQ_ACTIVE_INST_VALU"] * 64.0)
+        v[key + "/shade"] = {"kernel": shade, "active_lane_fraction": sl,
+                             "valu_active_per_wave_cycle": ss["SQ_ACTIVE_INST_VALU"] / ss["SQ_WAVE_CYCLES"],
+                             "wave_cycles_waiting_on_memory_or_barrier": ss["SQ_WAIT_ANY"] / ss["SQ_WAVE_CYCLES"],
+                             "wave_instructions_per_step": ss["SQ_INSTS_VALU"] / (ss["_dispatches"] / 50.0),
+                             "source": "profiles/%s_pmc_issue.txt" % tag, "kernel_sources": kernel_source_hash()}
     json.dump(v, open(path, "w"), indent=1)
     print(json.dumps(t[key], indent=1))
     print(json.dumps(v[key], indent=1))
