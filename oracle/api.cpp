@@ -129,7 +129,7 @@ int orc_scene_build(int scene_id, uint64_t seed, const RtSceneOptions* opt, OrcS
     bvh_lbvh = opt && (opt->flags & RT_SCENE_BVH_LBVH) != 0;
     try {
         s->world = build_scene(scene_id, o);
-        if (auto* root = dynamic_cast<BVHNode*>(s->world.get())) mark_world_boxes(s->world, root->_box);
+        if (s->world) s->world = std::make_shared<World>(s->world);
     } catch (const std::exception& e) {
         cur_ctx = nullptr; bvh_widest_axis = false; bvh_lbvh = false; delete s;
         return fail(RT_E_INVALID, e.what());
@@ -383,8 +383,7 @@ int orc_builder_finish(OrcBuilder* b, int root, OrcScene** out) {
     CHK(b->obj, root)
     if (!dynamic_cast<BVHNode*>(b->obj[(size_t)root].get())) return fail(RT_E_INVALID, "root must be a BVHNode");
     auto* s = new OrcScene();
-    s->world = b->obj[(size_t)root]; s->ctx = b->ctx; s->seed = b->seed;
-    mark_world_boxes(s->world, static_cast<BVHNode*>(s->world.get())->_box);
+    s->world = std::make_shared<World>(b->obj[(size_t)root]); s->ctx = b->ctx; s->seed = b->seed;
     *out = s;
     return 0;
 }

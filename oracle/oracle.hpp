@@ -63,6 +63,7 @@ struct Tls {
     uint64_t n_prim[K_NKINDS] = {};  // primitive hit() calls by kind
     uint64_t n_rays = 0;             // world.hit queries issued by ray_color
     bool in_boundary = false;        // inside the boundary queries of a ConstantMedium
+    bool deferred_pass = false;      // World::hit is putting the deferred media to the ray (GPU modes)
     std::vector<RayRecord>* recorder = nullptr;
     uint32_t record_max_bounce = 0;
 };
@@ -938,6 +939,10 @@ struct ConstantMedium : Hittable {  // :10-94
     MatPtr phase_function;
     double neg_inv_density;
     uint32_t id, rng_id;
+    // Not in the reference: a medium that every ray reaches (world space, under no box that is tested, boundary = one
+    // sphere) is taken out of the product's entry stream and put to the ray before everything else
+    // (World::hit below; collect_deferred_media decides). The GPU modes do the same, so that traversal work stays comparable.
+    mutable bool deferred = false;
     ConstantMedium(HitPtr b, double d, TexPtr a)
         : boundary(std::move(b)), phase_function(std::make_shared<Isotropic>(std::move(a))), neg_inv_density(-1.0 / d),
           id(take_prim_id()), rng_id(take_medium_id()) {}
@@ -945,6 +950,7 @@ struct ConstantMedium : Hittable {  // :10-94
         : boundary(std::move(b)), phase_function(std::make_shared<Isotropic>(c)), neg_inv_density(-1.0 / d),
           id(take_prim_id()), rng_id(take_medium_id()) {}
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :34-89
+        if (deferred && tls.aabb_mode != AABB_REFERENCE && !tls.deferred_pass) return false;  // its turn comes in World::hit
         ++tls.n_prim[K_MEDIUM];
         HitRecord rec1, rec2;
         struct Inside { bool was; Inside() : was(tls.in_boundary) { tls.in_boundary = true; } ~Inside() { tls.in_boundary = was; } };
@@ -1086,6 +1092,53 @@ inline void mark_world_boxes(const HitPtr& obj, const AABB& world) {
     mark_world_boxes(node->left, world);
     if (node->right.get() != node->left.get()) mark_world_boxes(node->right, world);
 }
+
+// The media that every ray reaches: found from the root through HittableLists and through BVHNodes that get no entry
+// (every other node's box may be missed), outside wrappers; boundary = one Sphere; at most two, in walk order.
+constexpr size_t K_MAX_DEFERRED_MEDIA = 2;
+inline void collect_deferred_media(const HitPtr& obj, std::vector<const ConstantMedium*>& out) {
+    if (auto* list = dynamic_cast<HittableList*>(obj.get())) {
+        for (const HitPtr& o : list->objects) collect_deferred_media(o, out);
+    } else if (auto* node = dynamic_cast<BVHNode*>(obj.get())) {
+        if (!node->no_entry) return;
+        collect_deferred_media(node->left, out);
+        if (node->right.get() != node->left.get()) collect_deferred_media(node->right, out);
+    } else if (auto* medium = dynamic_cast<ConstantMedium*>(obj.get())) {
+        if (out.size() < K_MAX_DEFERRED_MEDIA && dynamic_cast<Sphere*>(medium->boundary.get()) && !medium->deferred) {
+            medium->deferred = true;
+            out.push_back(medium);
+        }
+    }
+}
+
+// world.hit (src/color.rs:41) as the product searches the world: in the GPU modes the deferred media are asked first, as
+// if they stood first in the world's list, then the reference's walk with their hit as the closest so far. The medium's
+// candidate t does not depend on t_max (only its acceptance does) and its random number is keyed by the medium, so the
+// closest of all candidates comes out as in the reference's order, except when the medium's t and another object's t
+// agree to the last bits.
+struct World : Hittable {
+    HitPtr root;
+    std::vector<const ConstantMedium*> deferred;
+    explicit World(HitPtr r) : root(std::move(r)) {
+        if (auto* node = dynamic_cast<BVHNode*>(root.get())) mark_world_boxes(root, node->_box);
+        collect_deferred_media(root, deferred);
+    }
+    bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {
+        if (tls.aabb_mode == AABB_REFERENCE) return root->hit(r, t_min, t_max, rec);
+        bool any = false;
+        for (const ConstantMedium* m : deferred) {
+            tls.deferred_pass = true;
+            const bool h = m->hit(r, t_min, any ? rec.t : t_max, rec);
+            tls.deferred_pass = false;
+            any = any || h;
+        }
+        // like HittableList::hit (src/hittable.rs:151-164): the record is only written by what is hit within the range
+        HitRecord temp = rec;
+        if (root->hit(r, t_min, any ? rec.t : t_max, temp)) { rec = temp; any = true; }
+        return any;
+    }
+    bool bounding_box(double t0, double t1, AABB& output_box) const override { return root->bounding_box(t0, t1, output_box); }
+};
 
 // Boxes of six sides that are leaves of a tree get a culling box of their own (CullBox) when the list the tree is made
 // from holds at least this many of them; the product's flattener applies the same rule.

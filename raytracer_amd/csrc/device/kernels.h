@@ -17,11 +17,11 @@
 
 namespace rtd {
 
-struct alignas(32) RayRec {     // 96 bytes; extend reads the first 64
+struct alignas(32) RayRec {     // 96 bytes; extend reads the first 64, and the last 16 in scenes with media put to the ray first
     double o[3], d[3], tm;      // the ray handed to world.hit (src/ray.rs:3-7)
-    uint32_t slot, pad0;
+    uint32_t slot, first_ref;   // first_ref / first_t: the hit the walk starts from (see first_candidate), RT_MISS / +inf: none
     double T[3];                // throughput: product of attenuations so far
-    double pad1;
+    double first_t;
 };
 struct alignas(16) HitSlot {    // extend -> shade, indexed like the records
     double t;
@@ -40,7 +40,7 @@ constexpr uint32_t DEAD_SLOT = 0xFFFFFFFFu;
 constexpr uint32_t DEAD_REF = 0xFFFFFFFEu;   // HitSlot::ref of a padding record (no entry has kind 14)
 
 // 16-byte loads/stores of a record (global_load_dwordx4 / global_store_dwordx4)
-RT_D void load_ray64(const RayRec* r, V3& o, V3& d, double& tm, uint32_t& slot) {
+RT_D void load_ray64(const RayRec* r, V3& o, V3& d, double& tm, uint32_t& slot, uint32_t& first_ref) {
     const double2* p = reinterpret_cast<const double2*>(r);
     const double2 a = p[0], b = p[1], c = p[2];
     const uint4 e = reinterpret_cast<const uint4*>(r)[3];
@@ -48,22 +48,43 @@ RT_D void load_ray64(const RayRec* r, V3& o, V3& d, double& tm, uint32_t& slot) 
     d = v3(b.y, c.x, c.y);
     tm = __hiloint2double((int)e.y, (int)e.x);
     slot = e.z;
+    first_ref = e.w;
+}
+RT_D void load_ray64(const RayRec* r, V3& o, V3& d, double& tm, uint32_t& slot) {
+    uint32_t first_ref;
+    load_ray64(r, o, d, tm, slot, first_ref);
 }
 RT_D void load_throughput(const RayRec* r, V3& T) {
     const double2* p = reinterpret_cast<const double2*>(r);
     const double2 a = p[4], b = p[5];
     T = v3(a.x, a.y, b.x);
 }
-RT_D void store_ray(RayRec* r, V3 o, V3 d, double tm, uint32_t slot, V3 T) {
+RT_D void store_ray(RayRec* r, V3 o, V3 d, double tm, uint32_t slot, V3 T, const Cand& first) {
     double2* p = reinterpret_cast<double2*>(r);
     p[0] = make_double2(o.x, o.y);
     p[1] = make_double2(o.z, d.x);
     p[2] = make_double2(d.y, d.z);
     uint4 e;
-    e.x = (uint32_t)__double2loint(tm); e.y = (uint32_t)__double2hiint(tm); e.z = slot; e.w = 0u;
+    e.x = (uint32_t)__double2loint(tm); e.y = (uint32_t)__double2hiint(tm); e.z = slot; e.w = first.ref;
     reinterpret_cast<uint4*>(r)[3] = e;
     p[4] = make_double2(T.x, T.y);
-    p[5] = make_double2(T.z, 0.0);
+    p[5] = make_double2(T.z, first.t);
+}
+
+// The hit a world query starts from: in the reference's order a medium that every ray reaches is asked somewhere in
+// the middle of the walk; here such media (taken out of the entry stream, SceneT::deferred) are asked first, as if they
+// stood first in the world's list, and the walk then starts with their hit as the closest so far, which also spares
+// it everything behind that hit. The candidate is computed by whoever makes the ray (k_generate, the shade launch of the
+// previous bounce, k_step_pack: kernels with issue slots to spare) and travels in the ray's record. Returns the number
+// of Sphere::hit calls made (work counters).
+template <class SC>
+RT_D uint32_t first_candidate(const SC& S, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, V3 o, V3 d, double tmin, double tmax,
+                              Cand& first) {
+    first.t = tmax; first.ref = RT_MISS; first.aux = 0u;
+    if (S.deferred.n == 0u) return 0u;
+    RayKey key;
+    key.seed = seed; key.pixel = pixel; key.sample = sample; key.bounce = bounce;
+    return deferred_media(S, key, o, d, tmin, first);
 }
 
 struct RenderConst {
@@ -128,6 +149,7 @@ RT_D SceneT<true> stage_scene(const DevScene& S, const LdsPlan& plan) {
     L.texels = S.texels;
     L.n_nodes = S.n_nodes;
     L.carried_t0 = S.carried_t0; L.carried_t1 = S.carried_t1;
+    L.deferred = S.deferred;
     __syncthreads();
     return L;
 }
@@ -263,8 +285,21 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
                 const uint32_t mine = my_rank < avail ? c_next + my_rank : base + (my_rank - avail);
                 if (!busy && my_rank < take && mine < n) {
                     index = mine;
-                    if (io.fetch(index, ray)) {
-                        w.init(S, ray.o, ray.d, ray.tm, ray.tmin, ray.tmax);
+                    Cand first;
+                    if (io.fetch(index, ray, first)) {
+                        // the media that are not in the stream are asked first: the stand-alone queries do it here, the
+                        // render path gets the answer with the ray; instrumented launches ask again so that the work is counted
+                        if ((IO::FIRST_CANDIDATE_HERE || COUNT) && S.deferred.n != 0u) {
+                            const uint32_t queries = first_candidate(S, ray.key.seed, ray.key.pixel, ray.key.sample, ray.key.bounce, ray.o, ray.d,
+                                                                     ray.tmin, ray.tmax, first);
+                            if (COUNT) {
+                                work.entries += S.deferred.n + queries;
+                                work.prim[RT_N_MEDIUM] += S.deferred.n;
+                                work.prim[RT_N_SPHERE] += queries;
+                            }
+                        }
+                        w.init(S, ray.o, ray.d, ray.tm, ray.tmin, first.t);
+                        w.best.ref = first.ref;
                         busy = true;
                     } else {
                         io.skip(index);
@@ -304,12 +339,14 @@ struct TraceIO {
         RayKey key;
         RayAoS rs;
     };
+    static constexpr bool FIRST_CANDIDATE_HERE = true;
     RT_D uint32_t n() const { return (uint32_t)n_rays; }
-    RT_D bool fetch(uint32_t i, Ray& r) const {
+    RT_D bool fetch(uint32_t i, Ray& r, Cand& first) const {
         const RtRay* q = rays + i;
         r.o = v3p(q->o); r.d = v3p(q->d); r.tm = q->tm; r.tmin = q->tmin; r.tmax = q->tmax;
         r.key.seed = seed; r.key.pixel = q->pixel; r.key.sample = q->sample; r.key.bounce = q->bounce;
         r.rs.r = q;
+        first.t = q->tmax; first.ref = RT_MISS; first.aux = 0u;
         return true;
     }
     RT_D void skip(uint32_t) const {}
@@ -365,7 +402,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, 2) k_trace(DevScene S0, LdsPlan p
 }
 
 // ---- generate: camera rays of one batch (src/main.rs:206-209, src/camera.rs:61-71) ---------
-__global__ void __launch_bounds__(BLOCK) k_generate(RenderConst C, PathState P) {
+__global__ void __launch_bounds__(BLOCK) k_generate(DevScene S, RenderConst C, PathState P) {
     // A lane's record is 96 bytes, so lanes storing their own records would touch 48 cache lines per store
     // instruction; the wave lays its 64 records out in LDS instead and writes the 6 KiB out in address order.
     __shared__ uint4 s_rec[BLOCK / 64][64 * 6];
@@ -381,15 +418,9 @@ __global__ void __launch_bounds__(BLOCK) k_generate(RenderConst C, PathState P) 
             V3 o, d;
             double tm;
             camera_ray(C.cam, C.seed, C.width, C.height, x, y, pix, sample, o, d, tm);
-            double2* r = reinterpret_cast<double2*>(mine + lane * 6u);
-            r[0] = make_double2(o.x, o.y);
-            r[1] = make_double2(o.z, d.x);
-            r[2] = make_double2(d.y, d.z);
-            uint4 e;
-            e.x = (uint32_t)__double2loint(tm); e.y = (uint32_t)__double2hiint(tm); e.z = slot; e.w = 0u;
-            mine[lane * 6u + 3u] = e;
-            r[4] = make_double2(1.0, 1.0);
-            r[5] = make_double2(1.0, 0.0);
+            Cand first;
+            (void)first_candidate(S, C.seed, pix, sample, 0u, o, d, 0.0001, D_INF, first);
+            store_ray(reinterpret_cast<RayRec*>(mine + lane * 6u), o, d, tm, slot, v3(1.0, 1.0, 1.0), first);
             P.lr[slot] = 0.0; P.lg[slot] = 0.0; P.lb[slot] = 0.0;
         }
         // lanes read what other lanes of the wave wrote: the wave runs in lockstep and LDS keeps its order; the fence
@@ -424,10 +455,14 @@ struct ExtendIO {
         RayKey key;
         RayRecRef rs;
     };
+    static constexpr bool FIRST_CANDIDATE_HERE = false;  // it comes with the record
+    bool has_first;  // the scene has media that are asked first (wave-uniform)
     RT_D uint32_t n() const { return count; }
-    RT_D bool fetch(uint32_t i, Ray& r) const {  // false: a padding record, no ray
+    RT_D bool fetch(uint32_t i, Ray& r, Cand& first) const {  // false: a padding record, no ray
         uint32_t slot;
-        load_ray64(recs + i, r.o, r.d, r.tm, slot);
+        first.t = D_INF; first.ref = RT_MISS; first.aux = 0u;
+        load_ray64(recs + i, r.o, r.d, r.tm, slot, first.ref);
+        if (has_first) first.t = reinterpret_cast<const double2*>(recs + i)[5].y;
         r.rs.wo = r.o; r.rs.wd = r.d;
         r.key.seed = seed; r.key.pixel = slot % npix; r.key.sample = sample0 + slot / npix; r.key.bounce = bounce;
         return slot != DEAD_SLOT;
@@ -459,6 +494,7 @@ __global__ void __launch_bounds__(extend_block(LDS, PROFILE), extend_waves(LDS, 
     ExtendIO io;
     io.recs = P.rec[cur]; io.hits = P.hit; io.seed = C.seed; io.npix = C.npix; io.sample0 = C.sample0; io.bounce = bounce;
     io.count = bounce == 0u ? C.n_slots : counts[cur];
+    io.has_first = S0.deferred.n != 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[cur ^ 1u] = 0u;  // the array the following shade launch appends to
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
@@ -505,7 +541,7 @@ RT_D uint32_t shade_key(const SC& S, uint32_t ref) {
 // (no, nd) and the updated throughput T when the path goes on.
 template <class SC>
 RT_D bool shade_one(const SC& S, const RenderConst& C, const PathState& P, uint32_t bounce, V3 o, V3 d, double tm, uint32_t slot,
-                    uint4 h, V3& T, V3& no, V3& nd) {
+                    uint4 h, V3& T, V3& no, V3& nd, Cand& first) {
     Cand best;
     best.t = __hiloint2double((int)h.y, (int)h.x); best.ref = h.z; best.aux = h.w;
     if (best.ref == RT_MISS) {
@@ -528,7 +564,10 @@ RT_D bool shade_one(const SC& S, const RenderConst& C, const PathState& P, uint3
     T = elemul(T, attenuation);
     no = rec.p;
     nd = dout;
-    return bounce + 1u < C.max_depth;  // ray_color(depth - 1) returns black at depth 0 (:37-39)
+    if (bounce + 1u >= C.max_depth) return false;  // ray_color(depth - 1) returns black at depth 0 (:37-39)
+    // what the next world.hit starts from (media that are asked first)
+    (void)first_candidate(S, C.seed, slot % C.npix, C.sample0 + slot / C.npix, bounce + 1u, no, nd, 0.0001, D_INF, first);
+    return true;
 }
 
 // Where a shading wave writes its survivors: consecutive records of a range it reserves `chunk` records at a time
@@ -540,7 +579,7 @@ struct SurvivorOut {
     uint32_t chunk, o_next, o_end, survivors;
     // A lane storing its own 96-byte record makes the wave touch 48 cache lines per store instruction, each only in
     // part; the survivors are laid out in LDS in output order instead and copied out in address order.
-    RT_D void emit(bool alive, uint32_t lane, V3 no, V3 nd, double tm, uint32_t slot, V3 T) {
+    RT_D void emit(bool alive, uint32_t lane, V3 no, V3 nd, double tm, uint32_t slot, V3 T, const Cand& first) {
         const unsigned long long mask = __ballot(alive);
         if (!mask) return;
         const uint32_t cnt = (uint32_t)__popcll(mask);
@@ -553,7 +592,7 @@ struct SurvivorOut {
             o_end = base + want;
         }
         const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (alive) store_ray(reinterpret_cast<RayRec*>(stage + rank * 6u), no, nd, tm, slot, T);
+        if (alive) store_ray(reinterpret_cast<RayRec*>(stage + rank * 6u), no, nd, tm, slot, T, first);
         // lanes read what other lanes of the wave wrote: the wave runs in lockstep and LDS keeps its order; the fence
         // and the scheduling barrier keep the compiler from moving accesses across this point
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -670,8 +709,10 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
             const uint4 h = h_n;
             c = grab();
             request(c);
-            const bool alive = slot != DEAD_SLOT && shade_one(S, C, P, bounce, o, d, tm, slot, h, T, no, nd);
-            out.emit(alive, lane, no, nd, tm, slot, T);
+            Cand first;
+            first.t = D_INF; first.ref = RT_MISS; first.aux = 0u;
+            const bool alive = slot != DEAD_SLOT && shade_one(S, C, P, bounce, o, d, tm, slot, h, T, no, nd, first);
+            out.emit(alive, lane, no, nd, tm, slot, T, first);
         }
     }
   } else {
@@ -705,8 +746,10 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
             load_throughput(recs + i + stride, T_n);
             h_n = *reinterpret_cast<const uint4*>(P.hit + i + stride);
         }
-        const bool alive = slot != DEAD_SLOT && shade_one(S, C, P, bounce, o, d, tm, slot, h, T, no, nd);
-        out.emit(alive, lane, no, nd, tm, slot, T);
+        Cand first;
+        first.t = D_INF; first.ref = RT_MISS; first.aux = 0u;
+        const bool alive = slot != DEAD_SLOT && shade_one(S, C, P, bounce, o, d, tm, slot, h, T, no, nd, first);
+        out.emit(alive, lane, no, nd, tm, slot, T, first);
     }
   }
     out.finish(lane, ray_total);
@@ -735,7 +778,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, RT_SHADE_WAVES) k_shade(DevScene 
 // ---- one bounce on caller-supplied rays (rt_path_step) ------------------------------------------------
 // pack: ray idx[k] of the caller's array becomes record k of the current record array, with throughput 1 and the
 // slot its (pixel, sample) has in a render of these parameters; its radiance columns start at zero.
-__global__ void __launch_bounds__(BLOCK) k_step_pack(const RtRay* __restrict__ rays, const uint32_t* __restrict__ idx, uint32_t n,
+__global__ void __launch_bounds__(BLOCK) k_step_pack(DevScene S, uint64_t seed, const RtRay* __restrict__ rays, const uint32_t* __restrict__ idx, uint32_t n,
                                                      uint32_t npix, uint32_t sample_begin, PathState P, uint32_t cur,
                                                      uint32_t* __restrict__ slot_to_ray) {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
@@ -743,7 +786,9 @@ __global__ void __launch_bounds__(BLOCK) k_step_pack(const RtRay* __restrict__ r
     const uint32_t i = idx[k];
     const RtRay* q = rays + i;
     const uint32_t slot = (q->sample - sample_begin) * npix + q->pixel;
-    store_ray(P.rec[cur] + k, v3p(q->o), v3p(q->d), q->tm, slot, v3(1.0, 1.0, 1.0));
+    Cand first;
+    (void)first_candidate(S, seed, q->pixel, q->sample, q->bounce, v3p(q->o), v3p(q->d), 0.0001, D_INF, first);
+    store_ray(P.rec[cur] + k, v3p(q->o), v3p(q->d), q->tm, slot, v3(1.0, 1.0, 1.0), first);
     P.lr[slot] = 0.0; P.lg[slot] = 0.0; P.lb[slot] = 0.0;
     slot_to_ray[slot] = i;
 }

@@ -29,6 +29,16 @@ constexpr double D_INF = __builtin_huge_val();
 template <bool IN_LDS> struct TablePtr { template <class T> using type = const T*; };
 template <> struct TablePtr<true> { template <class T> using type = const RT_LDS T*; };
 
+// Media that every ray reaches (world space, under no box entry, boundary = one sphere: the fog of final_scene,
+// src/main.rs:656-662) are not walked as stream entries: the library takes them out of its copy of the stream and they
+// are put to the ray before the walk (deferred_media below).
+constexpr uint32_t MAX_DEFERRED_MEDIA = 2u;
+struct DeferredMedia {
+    uint32_t n;
+    uint32_t medium[MAX_DEFERRED_MEDIA];  // index into media
+    uint32_t sphere[MAX_DEFERRED_MEDIA];  // index into spheres: the boundary
+};
+
 template <bool IN_LDS>
 struct SceneT {
     template <class T> using P = typename TablePtr<IN_LDS>::template type<T>;
@@ -47,6 +57,7 @@ struct SceneT {
     const uint8_t* texels;
     uint32_t n_nodes;
     double carried_t0, carried_t1;  // ray times for which boxes marked RT_INNER_CARRIED / RT_INNER_COVER hold (PER_AXIS scenes)
+    DeferredMedia deferred;         // media taken out of the entry stream, see deferred_media()
 };
 using DevScene = SceneT<false>;
 
@@ -346,11 +357,11 @@ RT_D bool triangle_hit(PT tr, V3 o, V3 d, double tmin, double tmax, double& t_ou
 // so the roots are computed once and run through Sphere::hit's two range checks twice. `queries` = how many of
 // the two Sphere::hit calls the reference would have made (the second only after the first hit).
 template <class PS>
-RT_D bool sphere_boundary(PS s, const Seg& g, double& t1, double& t2, uint32_t& queries) {
+RT_D bool sphere_boundary(PS s, V3 o, V3 d, double dd, double& t1, double& t2, uint32_t& queries) {
     queries = 1u;
-    const V3 oc = g.o - v3p(s->c);
-    const double a = g.dd;
-    const double half_b = dot(oc, g.d);
+    const V3 oc = o - v3p(s->c);
+    const double a = dd;
+    const double half_b = dot(oc, d);
     const double c = squared_length(oc) - s->r * s->r;
     const double discriminant = half_b * half_b - a * c;
     if (!(discriminant > 0.0)) return false;
@@ -366,6 +377,52 @@ RT_D bool sphere_boundary(PS s, const Seg& g, double& t1, double& t2, uint32_t& 
     else if (rb < D_INF && rb > lo) t2 = rb;
     else return false;
     return true;
+}
+
+// ConstantMedium::hit after its two boundary queries, src/constant_medium.rs:52-88: [t1, t2] is where the ray is inside
+// the boundary, [tmin, best.t] the range of the query; dd = d . d; wrapper = innermost wrapper around the medium, table
+// index + 1, 0 = none. The one random number is keyed by the medium, so the outcome does not depend on what was searched before.
+template <class SC>
+RT_D void medium_resolve(const SC& S, const RayKey& key, uint32_t meta, double t1, double t2, double tmin, double dd, uint32_t wrapper,
+                         Cand& best) {
+    const auto m = S.media + (meta >> 4);
+    if (t1 < tmin) t1 = tmin;
+    if (t2 > best.t) t2 = best.t;
+    if (t1 > t2) return;
+    if (t1 < 0.0) t1 = 0.0;
+    const double ray_length = sqrt(dd);  // r.dire.length()
+    const double distance_inside_boundary = (t2 - t1) * ray_length;
+    rt::Rng rng;
+    rng.set_path(key.seed, key.pixel, key.sample, key.bounce, rt::RNG_MEDIUM0 + m->rng_id);
+    const double hit_distance = m->neg_inv_density * log10(rng.uniform(0.0, 1.0));  // :69
+    if (hit_distance > distance_inside_boundary) return;
+    best.t = t1 + hit_distance / ray_length;
+    best.ref = meta;
+    best.aux = wrapper << 8;
+}
+
+// The media that were taken out of the entry stream, put to the world ray (o, d): ConstantMedium::hit of each, in stream
+// order, with the closest hit so far as t_max. The kernels do this BEFORE the walk (first_candidate in kernels.h), as if
+// these media stood first in the world's list. In the reference's order such a medium is asked somewhere in the middle,
+// with the closest hit so far as t_max, and what comes after it with the medium's hit as t_max; the closest of all
+// candidates wins either way, because the medium's candidate t does not depend on t_max (only whether it is accepted
+// does) and its random number is keyed by the medium. The orders can differ only when the medium's t and another
+// object's t agree to the last bits (the medium's acceptance compares distances, the other objects compare t).
+// Returns the Sphere::hit calls the reference would have made (for the work counters).
+template <class SC>
+RT_D uint32_t deferred_media(const SC& S, const RayKey& key, V3 o, V3 d, double tmin, Cand& best) {
+    uint32_t sphere_queries = 0u;
+    const double dd = squared_length(d);
+#pragma unroll  // constant indices: the lists live in registers, not in scratch memory
+    for (uint32_t k = 0u; k < MAX_DEFERRED_MEDIA; ++k) {
+        if (k >= S.deferred.n) break;
+        double t1 = 0.0, t2 = 0.0;
+        uint32_t queries;
+        const bool inside = sphere_boundary(S.spheres + S.deferred.sphere[k], o, d, dd, t1, t2, queries);
+        sphere_queries += queries;
+        if (inside) medium_resolve(S, key, RT_N_MEDIUM | (S.deferred.medium[k] << 4), t1, t2, tmin, dd, 0u, best);
+    }
+    return sphere_queries;
 }
 
 #ifdef RT_DIAG_WAVE
@@ -425,20 +482,7 @@ struct Walker {
     // ConstantMedium::hit after its two boundary queries, src/constant_medium.rs:52-88
     template <class SC>
     RT_D void resolve_medium(const SC& S, const RayKey& key, uint32_t meta, double t1, double t2) {
-        const auto m = S.media + (meta >> 4);
-        if (t1 < tmin) t1 = tmin;
-        if (t2 > best.t) t2 = best.t;
-        if (t1 > t2) return;
-        if (t1 < 0.0) t1 = 0.0;
-        const double ray_length = sqrt(g.dd);  // r.dire.length()
-        const double distance_inside_boundary = (t2 - t1) * ray_length;
-        rt::Rng rng;
-        rng.set_path(key.seed, key.pixel, key.sample, key.bounce, rt::RNG_MEDIUM0 + m->rng_id);
-        const double hit_distance = m->neg_inv_density * log10(rng.uniform(0.0, 1.0));  // :69
-        if (hit_distance > distance_inside_boundary) return;
-        best.t = t1 + hit_distance / ray_length;
-        best.ref = meta;
-        best.aux = cur_xf << 8;
+        medium_resolve(S, key, meta, t1, t2, tmin, g.dd, cur_xf, best);
     }
 
     // Returns true when the lane stands on a non-box entry. With VOTE_DEN != 0 a lane also leaves,
@@ -641,7 +685,7 @@ struct Walker {
                     // boundary is one sphere: both queries from one quadratic
                     double t1 = 0.0, t2 = 0.0;
                     uint32_t queries;
-                    const bool inside = sphere_boundary(S.spheres + (first >> 4), g, t1, t2, queries);
+                    const bool inside = sphere_boundary(S.spheres + (first >> 4), g.o, g.d, g.dd, t1, t2, queries);
 #ifndef RT_DIAG_WAVE
                     if (COUNT) { work->entries += queries; work->prim[RT_N_SPHERE] += queries; }
 #endif
@@ -691,19 +735,5 @@ struct Walker {
         ++i;
     }
 };
-
-// One query start to finish (the stand-alone trace kernels).
-template <bool COUNT, class SC, class RS>
-RT_D void closest_hit(const SC& S, const RS& rs, V3 o0, V3 d0, double tm, double tmin0, double tmax0, const RayKey& key,
-                      Cand& best, Work* work) {
-    Walker<COUNT> w;
-    w.init(S, o0, d0, tm, tmin0, tmax0);
-    for (;;) {
-        if (!w.box_run(S, key, work)) break;
-        if (w.done) break;
-        w.leaf(S, rs, key, work);
-    }
-    best = w.best;
-}
 
 }  // namespace rtd

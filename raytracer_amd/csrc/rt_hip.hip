@@ -158,6 +158,50 @@ int validate(const RtSceneDesc* d) {
     return RT_OK;
 }
 
+// Media that every ray reaches: RT_N_MEDIUM entries in world space (inside no wrapper), under no box entry (no ray
+// skips them), whose boundary is one sphere. They leave the library's copy of the stream (`out` = the stream without
+// them, links moved) and are put to every ray after its walk instead (rtd::deferred_media): a walk spends a whole round
+// of a partly filled wave on such an entry, the shade launch handles it with full waves.
+void strip_unconditional_media(const RtSceneDesc* d, std::vector<RtNode>& out, rtd::DeferredMedia& df) {
+    df = rtd::DeferredMedia{};
+    std::vector<uint64_t> drop;  // positions of the medium entries taken out (each with the sphere entry after it)
+    uint64_t covered_until = 0;  // entries before this index lie under some box entry
+    uint32_t wrappers = 0;
+    for (uint64_t i = 0; i < d->n_nodes; ++i) {
+        const RtNode& n = d->nodes[i];
+        const uint32_t kind = n.meta & 15u;
+        if (kind == RT_N_XF_ENTER) ++wrappers;
+        if (kind == RT_N_XF_EXIT) --wrappers;
+        if (kind == RT_N_INNER) covered_until = std::max<uint64_t>(covered_until, n.link);
+        if (kind != RT_N_MEDIUM) continue;
+        const bool reached_by_all = i >= covered_until && wrappers == 0;
+        const bool one_sphere = n.link == i + 2 && (d->nodes[i + 1].meta & 15u) == RT_N_SPHERE;
+        if (reached_by_all && one_sphere && df.n < rtd::MAX_DEFERRED_MEDIA) {
+            df.medium[df.n] = n.meta >> 4;
+            df.sphere[df.n] = d->nodes[i + 1].meta >> 4;
+            ++df.n;
+            drop.push_back(i);
+        }
+        i = n.link - 1;  // nothing inside a boundary is looked at (no boxes that count, no media: validate())
+        covered_until = std::max<uint64_t>(covered_until, 0);
+    }
+    if (drop.empty()) return;
+    auto moved = [&](uint64_t pos) {  // where entry `pos` (or the end of the stream) stands afterwards
+        uint64_t before = 0;
+        for (uint64_t p : drop) if (p < pos) before += 2;
+        return pos - before;
+    };
+    out.reserve(d->n_nodes - 2 * drop.size());
+    size_t next_drop = 0;
+    for (uint64_t i = 0; i < d->n_nodes; ++i) {
+        if (next_drop < drop.size() && drop[next_drop] == i) { ++next_drop; ++i; continue; }
+        RtNode n = d->nodes[i];
+        const uint32_t kind = n.meta & 15u;
+        if (kind == RT_N_INNER || kind == RT_N_MEDIUM) n.link = (uint32_t)moved(n.link);
+        out.push_back(n);
+    }
+}
+
 template <class T>
 int upload(RtScene* s, const T* src, uint64_t n, const T** dst) {
     *dst = nullptr;
@@ -322,7 +366,7 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         C.sample0 = s0;
         C.n_slots = (uint32_t)(npix * ns);
         const uint32_t grid = grid_for(s, C.n_slots);
-        hipLaunchKernelGGL(rtd::k_generate, dim3(grid), dim3(rtd::BLOCK), 0, stream, C, w.P);
+        hipLaunchKernelGGL(rtd::k_generate, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, C, w.P);
         for (uint32_t bounce = 0; bounce < p->max_depth; ++bounce) {
             const uint32_t cur = bounce & 1u;
             if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
@@ -377,6 +421,13 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
     if (!out) return rt::set_error(RT_E_INVALID, "null output");
     *out = nullptr;
     if (int rc = validate(d)) return rc;
+    // the stream the kernels walk: the caller's without the media that every ray reaches
+    RtSceneDesc own = *d;
+    std::vector<RtNode> own_nodes;
+    rtd::DeferredMedia deferred{};
+    if (!std::getenv("RT_NO_DEFERRED_MEDIA")) strip_unconditional_media(d, own_nodes, deferred);  // developer knob: walk them in place
+    if (deferred.n) { own.nodes = own_nodes.data(); own.n_nodes = own_nodes.size(); }
+    d = &own;
     RtScene* s = new (std::nothrow) RtScene();
     if (!s) return rt::set_error(RT_E_NOMEM, "out of host memory");
     int rc = RT_OK;
@@ -562,6 +613,7 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         if ((rc = upload(s, d->images, d->n_images, &s->S.images))) break;
         if ((rc = upload(s, d->texels, d->n_texel_bytes, &s->S.texels))) break;
         s->S.n_nodes = (uint32_t)d->n_nodes;
+        s->S.deferred = deferred;
         // the ray times for which every moving sphere is within its own motion interval (RT_INNER_CARRIED / _COVER)
         s->S.carried_t0 = -rtd::D_INF; s->S.carried_t1 = rtd::D_INF;
         for (uint64_t i = 0; i < d->n_msphere; ++i) {
@@ -754,7 +806,7 @@ int rt_path_step(RtScene* s, const RtRenderParams* p, int profile, const RtRay* 
         const uint32_t counts_host[3] = {cur == 0u ? ng : 0u, cur == 1u ? ng : 0u, 0u};
         HIP_TRY(hipMemcpyAsync(w.counts, counts_host, sizeof counts_host, hipMemcpyHostToDevice, stream));
         const uint32_t grid = grid_for(s, ng);
-        hipLaunchKernelGGL(rtd::k_step_pack, dim3(grid), dim3(rtd::BLOCK), 0, stream, d_rays, d_idx + at, ng, (uint32_t)npix, p->sample_begin, w.P, cur, d_slot_to_ray);
+        hipLaunchKernelGGL(rtd::k_step_pack, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, p->seed, d_rays, d_idx + at, ng, (uint32_t)npix, p->sample_begin, w.P, cur, d_slot_to_ray);
         launch_extend(s, profile, work != nullptr, C, cur, bounce, stream);
         launch_shade(s, C, cur, bounce, stream);
         hipLaunchKernelGGL(rtd::k_step_unpack_hits, dim3(grid), dim3(rtd::BLOCK), 0, stream, s->S, d_idx + at, ng, w.P, cur, d_out);

@@ -68,9 +68,10 @@ def test_lean_extend_fits_four_waves(kernels, profile, lds):
     # what is spilled today: a handful of values of the refill / leaf code, 48 bytes per lane; more than that is a
     # spill that reached the box loop
     assert k["scratch"] <= 48 and k["vgpr_spills"] <= 8 and not k["dynamic_stack"], k
-    # the instrumented twin (work counters) keeps the occupancy, its counters may spill
+    # the instrumented twin (work counters; it also puts the media that are not in the stream to the ray itself) keeps
+    # the occupancy, its counters may spill; it is never timed
     c = kernels["rtd::k_extend<true, %s, %d>" % (lds, profile)]
-    assert c["occupancy"] == 4 and c["scratch"] <= 128, c
+    assert c["occupancy"] == 4 and c["scratch"] <= 400, c
 
 
 @pytest.mark.parametrize("lds", ["true", "false"])
@@ -91,6 +92,9 @@ def test_shade_fits_two_waves_without_scratch(kernels):
 
 
 def test_streaming_kernels_stay_small(kernels):
-    for name in ("rtd::k_generate", "rtd::k_accumulate", "rtd::k_resolve"):
+    for name in ("rtd::k_accumulate", "rtd::k_resolve"):
         k = kernels[name]
         assert k["scratch"] == 0 and k["vgprs"] <= 64 and k["occupancy"] >= 6, (name, k)
+    # k_generate also asks the media that every ray reaches (Philox, log10, two square roots): still bound by its writes
+    k = kernels["rtd::k_generate"]
+    assert k["scratch"] == 0 and k["vgprs"] <= 128 and k["occupancy"] >= 4, k
