@@ -939,10 +939,10 @@ struct ConstantMedium : Hittable {  // :10-94
     MatPtr phase_function;
     double neg_inv_density;
     uint32_t id, rng_id;
-    // Not in the reference: a medium that every ray reaches (world space, under no box that is tested, boundary = one
-    // sphere) is taken out of the product's entry stream and put to the ray before everything else
-    // (World::hit below; collect_deferred_media decides). The GPU modes do the same, so that traversal work stays comparable.
-    mutable bool deferred = false;
+    // Not in the reference: the product takes media in world space whose boundary is one sphere out of its entry stream
+    // and asks them before everything else (World::hit below; collect_deferred_media decides which). The GPU modes do
+    // the same, so that traversal work stays comparable. Bit m set: deferred in box mode m.
+    mutable uint32_t deferred_modes = 0;
     ConstantMedium(HitPtr b, double d, TexPtr a)
         : boundary(std::move(b)), phase_function(std::make_shared<Isotropic>(std::move(a))), neg_inv_density(-1.0 / d),
           id(take_prim_id()), rng_id(take_medium_id()) {}
@@ -950,7 +950,7 @@ struct ConstantMedium : Hittable {  // :10-94
         : boundary(std::move(b)), phase_function(std::make_shared<Isotropic>(c)), neg_inv_density(-1.0 / d),
           id(take_prim_id()), rng_id(take_medium_id()) {}
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :34-89
-        if (deferred && tls.aabb_mode != AABB_REFERENCE && !tls.deferred_pass) return false;  // its turn comes in World::hit
+        if (((deferred_modes >> tls.aabb_mode) & 1u) && !tls.deferred_pass) return false;  // World::hit has asked it already
         ++tls.n_prim[K_MEDIUM];
         HitRecord rec1, rec2;
         struct Inside { bool was; Inside() : was(tls.in_boundary) { tls.in_boundary = true; } ~Inside() { tls.in_boundary = was; } };
@@ -1015,6 +1015,8 @@ struct BVHNode : Hittable {  // :10-15
     // radius 5000) is passed by every ray that starts inside the world; the flattener gives such a node no entry, and
     // the GPU modes here skip its test (mark_world_boxes below). Skipping a box that holds its content changes no hit.
     bool no_entry = false;
+    // Everything below is a deferred medium (carried-interval mode): the product's stream has no entry for such a node
+    bool pruned = false;
     void motion_hull(double& lo, double& hi) const override {
         left->motion_hull(lo, hi);
         if (right.get() != left.get()) right->motion_hull(lo, hi);
@@ -1044,6 +1046,7 @@ struct BVHNode : Hittable {  // :10-15
     }
 
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {  // :101-111
+        if (pruned && tls.aabb_mode == AABB_TIGHT) return false;
         if (no_entry && tls.aabb_mode != AABB_REFERENCE) {
             bool hit_left = left->hit(r, t_min, t_max, rec);
             if (right.get() == left.get()) return hit_left;
@@ -1093,22 +1096,46 @@ inline void mark_world_boxes(const HitPtr& obj, const AABB& world) {
     if (node->right.get() != node->left.get()) mark_world_boxes(node->right, world);
 }
 
-// The media that every ray reaches: found from the root through HittableLists and through BVHNodes that get no entry
-// (every other node's box may be missed), outside wrappers; boundary = one Sphere; at most two, in walk order.
+// The media that are asked before the walk: ConstantMedium objects in world space (reached from the root through
+// HittableLists and BVHNodes, not through wrappers) whose boundary is one Sphere, the first K_MAX_DEFERRED_MEDIA in
+// walk order. Where boxes may not bound their contents (AABB_PER_AXIS_F32) only those that every ray reaches: below
+// nodes that get no entry.
 constexpr size_t K_MAX_DEFERRED_MEDIA = 2;
-inline void collect_deferred_media(const HitPtr& obj, std::vector<const ConstantMedium*>& out) {
+inline void collect_deferred_media(const HitPtr& obj, bool reached_by_all, std::vector<const ConstantMedium*>& tight,
+                                   std::vector<const ConstantMedium*>& per_axis) {
     if (auto* list = dynamic_cast<HittableList*>(obj.get())) {
-        for (const HitPtr& o : list->objects) collect_deferred_media(o, out);
+        for (const HitPtr& o : list->objects) collect_deferred_media(o, reached_by_all, tight, per_axis);
     } else if (auto* node = dynamic_cast<BVHNode*>(obj.get())) {
-        if (!node->no_entry) return;
-        collect_deferred_media(node->left, out);
-        if (node->right.get() != node->left.get()) collect_deferred_media(node->right, out);
+        const bool all = reached_by_all && node->no_entry;
+        collect_deferred_media(node->left, all, tight, per_axis);
+        if (node->right.get() != node->left.get()) collect_deferred_media(node->right, all, tight, per_axis);
     } else if (auto* medium = dynamic_cast<ConstantMedium*>(obj.get())) {
-        if (out.size() < K_MAX_DEFERRED_MEDIA && dynamic_cast<Sphere*>(medium->boundary.get()) && !medium->deferred) {
-            medium->deferred = true;
-            out.push_back(medium);
+        if (!dynamic_cast<Sphere*>(medium->boundary.get())) return;
+        if (tight.size() < K_MAX_DEFERRED_MEDIA && !(medium->deferred_modes & (1u << AABB_TIGHT))) {
+            medium->deferred_modes |= 1u << AABB_TIGHT;
+            tight.push_back(medium);
+        }
+        if (reached_by_all && per_axis.size() < K_MAX_DEFERRED_MEDIA && !(medium->deferred_modes & (1u << AABB_PER_AXIS_F32))) {
+            medium->deferred_modes |= 1u << AABB_PER_AXIS_F32;
+            per_axis.push_back(medium);
         }
     }
+}
+// Nodes with nothing but deferred media below (carried-interval mode) have no entry in the product's stream.
+inline bool prune_emptied_nodes(const HitPtr& obj) {
+    if (auto* list = dynamic_cast<HittableList*>(obj.get())) {
+        bool empty = !list->objects.empty();
+        for (const HitPtr& o : list->objects) empty = prune_emptied_nodes(o) && empty;
+        return empty;
+    }
+    if (auto* node = dynamic_cast<BVHNode*>(obj.get())) {
+        const bool l = prune_emptied_nodes(node->left);
+        const bool r = node->right.get() == node->left.get() ? l : prune_emptied_nodes(node->right);
+        node->pruned = l && r;
+        return node->pruned;
+    }
+    if (auto* medium = dynamic_cast<ConstantMedium*>(obj.get())) return (medium->deferred_modes & (1u << AABB_TIGHT)) != 0;
+    return false;
 }
 
 // world.hit (src/color.rs:41) as the product searches the world: in the GPU modes the deferred media are asked first, as
@@ -1118,15 +1145,16 @@ inline void collect_deferred_media(const HitPtr& obj, std::vector<const Constant
 // agree to the last bits.
 struct World : Hittable {
     HitPtr root;
-    std::vector<const ConstantMedium*> deferred;
+    std::vector<const ConstantMedium*> deferred_tight, deferred_per_axis;
     explicit World(HitPtr r) : root(std::move(r)) {
         if (auto* node = dynamic_cast<BVHNode*>(root.get())) mark_world_boxes(root, node->_box);
-        collect_deferred_media(root, deferred);
+        collect_deferred_media(root, true, deferred_tight, deferred_per_axis);
+        (void)prune_emptied_nodes(root);
     }
     bool hit(const Ray& r, double t_min, double t_max, HitRecord& rec) const override {
         if (tls.aabb_mode == AABB_REFERENCE) return root->hit(r, t_min, t_max, rec);
         bool any = false;
-        for (const ConstantMedium* m : deferred) {
+        for (const ConstantMedium* m : tls.aabb_mode == AABB_TIGHT ? deferred_tight : deferred_per_axis) {
             tls.deferred_pass = true;
             const bool h = m->hit(r, t_min, any ? rec.t : t_max, rec);
             tls.deferred_pass = false;

@@ -292,11 +292,15 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
                         if ((IO::FIRST_CANDIDATE_HERE || COUNT) && S.deferred.n != 0u) {
                             const uint32_t queries = first_candidate(S, ray.key.seed, ray.key.pixel, ray.key.sample, ray.key.bounce, ray.o, ray.d,
                                                                      ray.tmin, ray.tmax, first);
+#ifdef RT_DIAG_WAVE
+                            (void)queries;  // the diagnostic build counts the executions of the walk's own phases only
+#else
                             if (COUNT) {
                                 work.entries += S.deferred.n + queries;
                                 work.prim[RT_N_MEDIUM] += S.deferred.n;
                                 work.prim[RT_N_SPHERE] += queries;
                             }
+#endif
                         }
                         w.init(S, ray.o, ray.d, ray.tm, ray.tmin, first.t);
                         w.best.ref = first.ref;
