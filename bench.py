@@ -322,6 +322,8 @@ def main():
         ms_extend += st.ms_extend
         ms_shade += st.ms_shade
         rays += st.rays
+    torch.cuda.synchronize()
+    own_render = time.perf_counter() - t0  # this rank's renders alone, before it meets the others in the all-reduce
     if rehearsal and world > 1:
         host = accum.cpu()
         allreduce_accum(host)
@@ -330,10 +332,12 @@ def main():
         allreduce_accum(accum)
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = {"min": own_render * 1e3 / args.steps, "max": own_render * 1e3 / args.steps}
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        t = torch.tensor([elapsed, own_render, -own_render], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        rank_ms = {"min": -float(t[2].item()) * 1e3 / args.steps, "max": float(t[1].item()) * 1e3 / args.steps}
 
     samples_total = (W * H * args.spp if strong else world * W * H * S) * args.steps
     own_samples = (W * H * (hi - lo) if strong else W * H * S) * args.steps  # of this rank, what `rays` counts
@@ -399,6 +403,9 @@ def main():
                        "sharding": "sample ranges per rank, one RCCL all-reduce of the f32 accumulation buffer",
                        **({"spp_total": args.spp, "spp_this_rank": hi - lo, "batches_per_step": len(batches), "spp_per_batch": S} if strong
                           else {"spp_per_step_per_gpu": S})},
+            # per step: the fastest and the slowest rank's own render time (imbalance between the ranks), and what the
+            # all-reduce and the waiting for the slowest rank add on top
+            "rank_render_ms_per_step": rank_ms, "allreduce_and_wait_ms_per_step": elapsed * 1e3 / args.steps - rank_ms["max"],
             "mrays_per_s": rays / max(1, own_samples) * samples_total / elapsed / 1e6,
             "rays_per_sample": rays / max(1, own_samples),
             "roofline": roofline,

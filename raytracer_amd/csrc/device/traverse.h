@@ -73,7 +73,10 @@ RT_D void load_node(const RtNode* p, uint4& a, uint4& b) {
 }
 RT_D void load_node(const RT_LDS RtNode* p, uint4& a, uint4& b) {
     const RT_LDS u32x4* q = reinterpret_cast<const RT_LDS u32x4*>(p);
-    const u32x4 x = q[0], y = q[1];
+    u32x4 x = q[0], y = q[1];
+#ifdef RT_LDS_BOTH_HALVES
+    asm volatile("" : "+v"(x), "+v"(y));
+#endif
     a = make_uint4(x.x, x.y, x.z, x.w);
     b = make_uint4(y.x, y.y, y.z, y.w);
 }
