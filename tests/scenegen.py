@@ -144,3 +144,26 @@ def aimed_rays(rng, n, radius=14.0, extent=5.0):
     rays["d"] = rng.uniform(-extent, extent, (n, 3)) - org
     rays["tmin"], rays["tmax"] = 1e-4, np.inf
     return rays
+
+
+def media_scene_pair(rtlib, orc, seed=5):
+    """Media of every standing the product's first-asked rule tells apart: five bounded by one sphere in world space (the
+    first two in walk order are asked before the walk, the others inside it), one of those enclosing the whole scene (every
+    ray reaches it), one bounded by a sphere inside a Translate (walked), one inside a rotated wrapper around a list,
+    among opaque spheres and a box, all under one tree."""
+    rng = np.random.default_rng(seed)
+    cs = rng.uniform(-4, 4, (12, 3))
+    roots = []
+    for api in (rtlib.host, orc.api):
+        b = api.builder(seed=seed)
+        lam, metal, glass = b.lambertian([0.6, 0.5, 0.4]), b.metal([0.8, 0.8, 0.9], 0.2), b.dielectric(1.5)
+        objs = [b.sphere(cs[k], 0.5 + 0.05 * k, [lam, metal, glass][k % 3]) for k in range(4)]
+        objs.append(b.constant_medium(b.sphere([0.0, 0.0, 0.0], 40.0, lam), 0.02, [1.0, 1.0, 1.0]))       # around everything
+        for k in range(4, 8):
+            objs.append(b.constant_medium(b.sphere(cs[k], 0.9, glass), 0.4 + 0.2 * k, [0.2, 0.4, 0.9]))
+        objs.append(b.constant_medium(b.translate(b.sphere(cs[8], 0.8, lam), [0.5, -0.25, 0.125]), 0.7, [0.7, 0.3, 0.3]))
+        inner = b.list([b.constant_medium(b.sphere(cs[9], 0.7, lam), 0.9, [0.1, 0.9, 0.1]), b.sphere(cs[10], 0.4, metal)])
+        objs.append(b.rotate_y(b.bvh(inner), 25.0))
+        objs.append(b.box6(cs[11], cs[11] + [1.0, 0.8, 0.6], lam))
+        roots.append(b.finish(b.bvh(b.list(objs), 0.0, 1.0)))
+    return roots

@@ -13,7 +13,7 @@ import pytest
 import oracle
 from conftest import CONFIG_SCENES, SEED, oracle_mode, scene_kwargs
 from raytracer_amd import abi, lib
-from scenegen import aimed_rays, clipping_scene_pair, nested_cover_scene_pair, nested_interval_scene_pair, random_rays, random_scene_pair
+from scenegen import aimed_rays, clipping_scene_pair, media_scene_pair, nested_cover_scene_pair, nested_interval_scene_pair, random_rays, random_scene_pair
 
 
 def same_hits(a, b, what):
@@ -164,5 +164,22 @@ def test_outer_tree_over_the_motion_around_an_inner_tree_that_is_not(orc, rtlib)
     assert (ref["prim_id"] != abi.RT_MISS).sum() > 8000
     differ = (mine["prim_id"] != ref["prim_id"]) | (mine["t"].view(np.uint64) != ref["t"].view(np.uint64))
     assert differ.sum() <= 2, differ.sum()  # (12 of the first 60 000 when the outer nodes were marked as holding)
+    hs.close()
+    orc.api.scene_free(oroot)
+
+
+def test_media_asked_before_the_walk(orc, rtlib):
+    # The product takes world-space media bounded by one sphere out of its entry stream and asks them before the walk; the
+    # oracle's mirrored modes do the same (World::hit). Against the reference's order, in which such a medium is asked
+    # where it stands in the tree: the same closest hit for rays of every kind of range (tmin below zero, finite tmax).
+    hroot, oroot = media_scene_pair(rtlib, orc)
+    hs = lib.HostScene(rtlib, hroot)
+    rays = random_rays(np.random.default_rng(99), 40000)
+    mine, _, st = orc.trace(oroot, rays, seed=31, mode=oracle_mode(hs))
+    ref, _, rst = orc.trace(oroot, rays, seed=31, mode=oracle.AABB_REFERENCE)
+    same_hits(mine, ref, "media scene")
+    assert st["medium"] > rst["medium"]  # the two media asked first are asked by every ray
+    hit_ids = set(int(x) for x in mine["prim_id"] if x != abi.RT_MISS)
+    assert len(hit_ids) >= 10
     hs.close()
     orc.api.scene_free(oroot)

@@ -10,7 +10,7 @@ import pytest
 import oracle
 from conftest import CONFIG_SCENES, SCENE_OPTS, SEED, load_golden, scene_kwargs, ulp_diff, oracle_mode
 from raytracer_amd import abi, lib
-from scenegen import aimed_rays, clipping_scene_pair, nested_cover_scene_pair, nested_interval_scene_pair, random_rays, random_scene_pair
+from scenegen import aimed_rays, clipping_scene_pair, media_scene_pair, nested_cover_scene_pair, nested_interval_scene_pair, random_rays, random_scene_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -161,6 +161,50 @@ def test_random_scenes_all_primitive_kinds(gpu, orc, case):
     assert np.array_equal(orec["front_face"], grec["front_face"])
     assert np.allclose(orec["normal"][hit], grec["normal"][hit], rtol=0, atol=1e-15)
     assert np.allclose(orec["p"][hit], grec["p"][hit], rtol=1e-13, atol=1e-11)
+    ds.close()
+    hs.close()
+    orc.api.scene_free(oroot)
+
+
+def test_media_asked_before_the_walk(gpu, orc, monkeypatch):
+    # World-space media bounded by one sphere leave the library's copy of the entry stream (the first two in walk order)
+    # and are asked before the walk. Same hits as the oracle doing likewise (and the same work), as the reference's own
+    # order (oracle in its reference mode), and as the library walking them in place.
+    hroot, oroot = media_scene_pair(gpu, orc)
+    hs = lib.HostScene(gpu, hroot)
+    rng = np.random.default_rng(99)
+    rays = random_rays(rng, 40000)
+    oh, _, ost = orc.trace(oroot, rays, seed=31, mode=oracle_mode(hs))
+    assert len(set(oh["prim_id"][oh["prim_id"] != abi.RT_MISS])) >= 10  # every kind of medium above is among the hits
+    ref, _, ost_ref = orc.trace(oroot, rays, seed=31, mode=oracle.AABB_REFERENCE)
+    assert np.array_equal(ref["prim_id"], oh["prim_id"]) and np.array_equal(ref["t"].view(np.uint64), oh["t"].view(np.uint64))
+    ds = lib.DeviceScene(hs)
+    gh, work = ds.trace_work(rays, seed=31)
+    compare_hits(oh, gh, "media scene")
+    assert work["inner"] == ost["box_tests"] and work["sphere"] == ost["sphere"] and work["medium"] == ost["medium"]
+    assert ost["medium"] > ost_ref["medium"]  # two media are now asked by every ray, not only by those that reach them
+    ds.close()
+    monkeypatch.setenv("RT_NO_DEFERRED_MEDIA", "1")  # read when a scene is created: the caller's stream as it stands
+    walked = lib.DeviceScene(hs)
+    wh, wwork = walked.trace_work(rays, seed=31)
+    assert np.array_equal(wh["prim_id"], gh["prim_id"]) and np.array_equal(wh["sub"], gh["sub"])
+    assert np.array_equal(wh["t"].view(np.uint64), gh["t"].view(np.uint64))
+    assert wwork["medium"] < work["medium"]  # walked in place, a medium is only asked by the rays that reach it
+    walked.close()
+    # the same through one bounce of the render kernels, where the answer travels with the ray record
+    monkeypatch.delenv("RT_NO_DEFERRED_MEDIA")
+    ds = lib.DeviceScene(hs)
+    world = rays[(rays["tmin"] == 1e-4) & np.isinf(rays["tmax"])].copy()
+    world["pixel"] = np.arange(len(world)) % (64 * 64)
+    world["sample"] = np.arange(len(world)) // (64 * 64)
+    world["bounce"] %= 50
+    p = lib.make_params(64, 64, 0, int(world["sample"].max()) + 1, [0.1, 0.2, 0.3], seed=31)
+    steps = ds.path_step(p, world)
+    osteps = orc.path_step(oroot, orc.make_params(64, 64, 0, int(world["sample"].max()) + 1, [0.1, 0.2, 0.3], seed=31), world, mode=oracle_mode(hs))
+    assert np.array_equal(steps["prim_id"], osteps["prim_id"]) and np.array_equal(steps["sub"], osteps["sub"])
+    hit = osteps["prim_id"] != abi.RT_MISS
+    assert ulp_diff(osteps["t"][hit], steps["t"][hit]).max(initial=0) <= T_ULP
+    assert np.array_equal(steps["scattered"], osteps["scattered"])
     ds.close()
     hs.close()
     orc.api.scene_free(oroot)
