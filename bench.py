@@ -346,6 +346,13 @@ def main():
         scratch = torch.zeros_like(accum)
         s0 = args.warmup * world * S
         wst, work = ds.render_work(cam, lib.make_params(W, H, s0, s0 + S, bg, samples_per_batch=S), scratch.data_ptr(), stream)
+        # Media that the library asks before the walk (world-space media bounded by one sphere: the kernel that makes a ray
+        # puts them to it, k_generate or the previous bounce's k_shade) are counted by the instrumented pass but are not
+        # work of the closest-hit launches: they come off k_extend's account and are reported on their own.
+        first = {"medium": work.pop("first_media"), "sphere": work.pop("first_spheres")}
+        for k in first:
+            work[k] -= first[k]
+            work["entries"] -= first[k]
         bytes_per_ray = algorithmic_bytes(wst.rays, work) / max(1, wst.rays)
         flops_per_ray = algorithmic_flops(work) / max(1, wst.rays)
         launches = max(1, launches[0])
@@ -375,7 +382,10 @@ def main():
                     "visits_per_ray": {k: round(work[k] / max(1, wst.rays), 4) for k in ROW_BYTES},
                     "ms_extend_per_step": ms_extend / args.steps, "ms_shade_per_step": ms_shade / args.steps,
                     "avg_launch_ms": ms_extend / launches, "launches": launches,
-                    "tables_in_lds": in_lds, "table_bytes": table_bytes}
+                    "tables_in_lds": in_lds, "table_bytes": table_bytes,
+                    "asked_before_the_walk": {"per_ray": {k: round(first[k] / max(1, wst.rays), 4) for k in first},
+                                              "flops_per_ray": sum(FLOPS[k] * first[k] for k in first) / max(1, wst.rays),
+                                              "done_by": "k_generate (camera rays) and k_shade (the rays it makes); not in k_extend's figures"}}
         # The second kernel of a bounce. Algorithmic bytes of the shade launches of one step: every ray's 96-byte record
         # and 16-byte hit slot in, a 96-byte record out per ray that goes on (every ray after the camera rays is such a
         # survivor), and the three 8-byte radiance columns read and written back for a path that gathers light.

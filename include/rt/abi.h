@@ -247,8 +247,10 @@ int rt_render_device(RtScene* scene, const RtCamera* cam, const RtRenderParams* 
 
 /* Instrumented rt_render_device: same image, and the traversal work of all extend launches of the call summed
  * into work[0 .. 9] (layout as in rt_trace_work); work[10] = path slots that gathered light (whose radiance
- * columns the shade launches read, added to and wrote back), work[11] = 0. 12 words. Waits for completion. Used
- * to derive the algorithmic bytes of the closest-hit and shade launches. */
+ * columns the shade launches read, added to and wrote back); work[11], work[12] = the part of work[1 + RT_N_MEDIUM] and
+ * work[1 + RT_N_SPHERE] that the closest-hit launches did not do themselves: media that are asked before the walk by
+ * the kernel that makes the ray, and the Sphere::hit calls of their boundaries; work[13] = 0. 14 words. Waits for
+ * completion. Used to derive the algorithmic bytes and operations of the closest-hit and shade launches. */
 int rt_render_work(RtScene* scene, const RtCamera* cam, const RtRenderParams* params, float* accum_rgb_dev, void* stream,
                    RtRenderStats* stats, uint64_t* work);
 

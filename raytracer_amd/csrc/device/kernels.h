@@ -75,16 +75,19 @@ RT_D void store_ray(RayRec* r, V3 o, V3 d, double tm, uint32_t slot, V3 T, const
 // the middle of the walk; here such media (taken out of the entry stream, SceneT::deferred) are asked first, as if they
 // stood first in the world's list, and the walk then starts with their hit as the closest so far, which also spares
 // it everything behind that hit. The candidate is computed by whoever makes the ray (k_generate, the shade launch of the
-// previous bounce, k_step_pack: kernels with issue slots to spare) and travels in the ray's record. Returns the number
-// of Sphere::hit calls made (work counters).
+// previous bounce, k_step_pack: kernels with issue slots to spare) and travels in the ray's record. Returns the boundary
+// queries made (work counters).
 template <class SC>
-RT_D uint32_t first_candidate(const SC& S, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, V3 o, V3 d, double tmin, double tmax,
-                              Cand& first) {
+RT_D FirstWork first_candidate(const SC& S, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, V3 o, V3 d, double tmin, double tmax,
+                               Cand& first) {
     first.t = tmax; first.ref = RT_MISS; first.aux = 0u;
-    if (S.deferred.n == 0u) return 0u;
+    FirstWork fw;
+    fw.spheres = 0u;
+    if (S.deferred.n == 0u) return fw;
     RayKey key;
     key.seed = seed; key.pixel = pixel; key.sample = sample; key.bounce = bounce;
-    return deferred_media(S, key, o, d, tmin, first);
+    deferred_media(S, key, o, d, tmin, first, fw);
+    return fw;
 }
 
 struct RenderConst {
@@ -230,7 +233,7 @@ constexpr uint32_t OUT_MIN_CHUNKS = RT_OUT_MIN_CHUNKS;  // ... "many" = at least
 template <bool COUNT, bool BOXMEDIA, bool GENERAL, uint32_t VOTE_DEN, bool PER_AXIS, class SC, class IO>
 RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsigned long long* __restrict__ work_out) {
     Work work;
-    if (COUNT) { work.entries = 0; for (int k = 0; k < 9; ++k) work.prim[k] = 0; }
+    if (COUNT) { work.entries = 0; for (int k = 0; k < 9; ++k) work.prim[k] = 0; work.first_media = 0; work.first.spheres = 0; }
     const uint32_t n = io.n();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total_waves = gridDim.x * (blockDim.x / 64u);
@@ -290,15 +293,17 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
                         // the media that are not in the stream are asked first: the stand-alone queries do it here, the
                         // render path gets the answer with the ray; instrumented launches ask again so that the work is counted
                         if ((IO::FIRST_CANDIDATE_HERE || COUNT) && S.deferred.n != 0u) {
-                            const uint32_t queries = first_candidate(S, ray.key.seed, ray.key.pixel, ray.key.sample, ray.key.bounce, ray.o, ray.d,
-                                                                     ray.tmin, ray.tmax, first);
+                            const FirstWork fw = first_candidate(S, ray.key.seed, ray.key.pixel, ray.key.sample, ray.key.bounce, ray.o, ray.d,
+                                                                 ray.tmin, ray.tmax, first);
 #ifdef RT_DIAG_WAVE
-                            (void)queries;  // the diagnostic build counts the executions of the walk's own phases only
+                            (void)fw;  // the diagnostic build counts the executions of the walk's own phases only
 #else
-                            if (COUNT) {
-                                work.entries += S.deferred.n + queries;
+                            if (COUNT) {  // what the walk would have counted had these media stood in the stream
+                                work.entries += S.deferred.n + fw.spheres;
                                 work.prim[RT_N_MEDIUM] += S.deferred.n;
-                                work.prim[RT_N_SPHERE] += queries;
+                                work.prim[RT_N_SPHERE] += fw.spheres;
+                                work.first_media += S.deferred.n;
+                                work.first.spheres += fw.spheres;
                             }
 #endif
                         }
@@ -328,6 +333,11 @@ RT_D void extend_pool(const SC& S, IO& io, uint32_t* __restrict__ cursor, unsign
     if (COUNT) {
         atomicAdd(work_out + 0, (unsigned long long)work.entries);
         for (int k = 0; k < 9; ++k) atomicAdd(work_out + 1 + k, (unsigned long long)work.prim[k]);
+        // words 11 and 12 of the counter block (word 10 belongs to k_accumulate): the part of the above that was not walked
+        if (work.first_media) {
+            atomicAdd(work_out + 11, (unsigned long long)work.first_media);
+            atomicAdd(work_out + 12, (unsigned long long)work.first.spheres);
+        }
     }
 }
 

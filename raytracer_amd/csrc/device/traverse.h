@@ -29,14 +29,18 @@ constexpr double D_INF = __builtin_huge_val();
 template <bool IN_LDS> struct TablePtr { template <class T> using type = const T*; };
 template <> struct TablePtr<true> { template <class T> using type = const RT_LDS T*; };
 
-// Media that every ray reaches (world space, under no box entry, boundary = one sphere: the fog of final_scene,
-// src/main.rs:656-662) are not walked as stream entries: the library takes them out of its copy of the stream and they
-// are put to the ray before the walk (deferred_media below).
+// Media in world space whose boundary is one sphere (the fog and the ball of smoke of final_scene, src/main.rs:642-662)
+// are not walked as stream entries: the library takes them out of its copy of the stream and they are put to the ray
+// before the walk (deferred_media below).
 constexpr uint32_t MAX_DEFERRED_MEDIA = 2u;
 struct DeferredMedia {
     uint32_t n;
     uint32_t medium[MAX_DEFERRED_MEDIA];  // index into media
     uint32_t sphere[MAX_DEFERRED_MEDIA];  // index into spheres: the boundary
+};
+// boundary queries made by deferred_media, as the reference would have made them (for the work counters)
+struct FirstWork {
+    uint32_t spheres;  // Sphere::hit calls
 };
 
 template <bool IN_LDS>
@@ -98,6 +102,8 @@ struct Cand {
 struct Work {
     uint32_t entries;   // stream entries fetched (32 B each)
     uint32_t prim[9];   // entries visited by RtNodeKind (the RT_N_INNER slot counts box tests)
+    uint32_t first_media;  // of those: media asked before the walk ...
+    FirstWork first;       // ... and the queries of their boundaries
 };
 
 // Where the world-space ray of a query lives in memory.
@@ -411,10 +417,9 @@ RT_D void medium_resolve(const SC& S, const RayKey& key, uint32_t meta, double t
 // candidates wins either way, because the medium's candidate t does not depend on t_max (only whether it is accepted
 // does) and its random number is keyed by the medium. The orders can differ only when the medium's t and another
 // object's t agree to the last bits (the medium's acceptance compares distances, the other objects compare t).
-// Returns the Sphere::hit calls the reference would have made (for the work counters).
 template <class SC>
-RT_D uint32_t deferred_media(const SC& S, const RayKey& key, V3 o, V3 d, double tmin, Cand& best) {
-    uint32_t sphere_queries = 0u;
+RT_D void deferred_media(const SC& S, const RayKey& key, V3 o, V3 d, double tmin, Cand& best, FirstWork& fw) {
+    fw.spheres = 0u;
     const double dd = squared_length(d);
 #pragma unroll  // constant indices: the lists live in registers, not in scratch memory
     for (uint32_t k = 0u; k < MAX_DEFERRED_MEDIA; ++k) {
@@ -422,10 +427,9 @@ RT_D uint32_t deferred_media(const SC& S, const RayKey& key, V3 o, V3 d, double 
         double t1 = 0.0, t2 = 0.0;
         uint32_t queries;
         const bool inside = sphere_boundary(S.spheres + S.deferred.sphere[k], o, d, dd, t1, t2, queries);
-        sphere_queries += queries;
+        fw.spheres += queries;
         if (inside) medium_resolve(S, key, RT_N_MEDIUM | (S.deferred.medium[k] << 4), t1, t2, tmin, dd, 0u, best);
     }
-    return sphere_queries;
 }
 
 #ifdef RT_DIAG_WAVE

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -22,7 +23,8 @@ using rtd::RenderConst;
 constexpr uint64_t kDefaultSlotTarget = 640ull << 20;  // path slots per wavefront batch when the caller does not say (145 GiB)
 constexpr uint64_t kBytesPerSlot = 2 * sizeof(rtd::RayRec) + sizeof(rtd::HitSlot) + 3 * sizeof(double);
 constexpr int kWorkWords = 10;                      // entries + 9 kinds
-constexpr int kRenderWorkWords = 12;                // rt_render_work: the same + slots that gathered light + one spare word
+constexpr int kRenderWorkWords = 14;                // rt_render_work: the same + slots that gathered light + media asked before the walk, their sphere queries + a spare word
+constexpr int kCounterWords = 16;                   // size of every device counter block the kernels write into
 
 #define HIP_TRY(expr)                                                                                      \
     do {                                                                                                   \
@@ -160,7 +162,8 @@ int validate(const RtSceneDesc* d) {
 
 // Media that are asked before the walk instead of inside it (rtd::deferred_media, rtd::first_candidate): RT_N_MEDIUM
 // entries in world space (inside no wrapper) whose boundary is one sphere, the first rtd::MAX_DEFERRED_MEDIA of them in
-// stream order. What a medium answers does not depend on when it is asked (its random number is keyed by the medium),
+// stream order (box-bounded media such as cornell_smoke's were tried too: their twelve divisions per medium cost the
+// shade launch as much as the walk saves). What a medium answers does not depend on when it is asked (its random number is keyed by the medium),
 // and a walk spends a whole round of a thinly filled wave on such an entry (measured on final_scene: 11 % of the lanes
 // for the medium inside the glass sphere), while the kernels that make rays ask with full waves. They leave the
 // library's copy of the stream (`out` = the stream without them, links moved), and box entries that are left with
@@ -256,7 +259,7 @@ int ensure_workspace(RtScene* s, uint64_t n_slots) {
     Workspace& w = s->ws;
     if (!w.counts) {
         HIP_TRY(hipMalloc((void**)&w.counts, 4 * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&w.ray_total, (1 + kRenderWorkWords) * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&w.ray_total, (1 + kCounterWords) * sizeof(unsigned long long)));
     }
     if (w.cap_slots >= n_slots) return RT_OK;
     if (w.base) { HIP_TRY(hipFree(w.base)); w.base = nullptr; w.cap_slots = 0; }
@@ -366,7 +369,7 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         w.events.push_back(e);
     }
     size_t ev = 0;
-    HIP_TRY(hipMemsetAsync(w.ray_total, 0, (1 + kRenderWorkWords) * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(w.ray_total, 0, (1 + kCounterWords) * sizeof(unsigned long long), stream));
     HIP_TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), stream));
     if (stats) HIP_TRY(hipEventRecord(w.events[ev++], stream));
     for (uint32_t b = 0; b < n_batches; ++b) {
@@ -395,10 +398,13 @@ int render_on_stream(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         HIP_TRY(hipEventElapsedTime(&ms, w.events[0], w.events[ev - 1]));
         stats->ms_total = ms;
         size_t k = 1;
+        const bool log_bounces = std::getenv("RT_BOUNCE_LOG") != nullptr;  // developer knob: the launches of every bounce on stderr
         for (uint32_t b = 0; b < n_batches; ++b)
             for (uint32_t bounce = 0; bounce < p->max_depth; ++bounce) {
-                HIP_TRY(hipEventElapsedTime(&ms, w.events[k], w.events[k + 1])); stats->ms_extend += ms;
-                HIP_TRY(hipEventElapsedTime(&ms, w.events[k + 1], w.events[k + 2])); stats->ms_shade += ms;
+                float me = 0.f, msh = 0.f;
+                HIP_TRY(hipEventElapsedTime(&me, w.events[k], w.events[k + 1])); stats->ms_extend += me;
+                HIP_TRY(hipEventElapsedTime(&msh, w.events[k + 1], w.events[k + 2])); stats->ms_shade += msh;
+                if (log_bounces) std::fprintf(stderr, "batch %u bounce %2u extend %9.4f ms shade %9.4f ms\n", b, bounce, me, msh);
                 k += 3;
             }
         unsigned long long rays = 0;
@@ -681,13 +687,13 @@ int trace_host(RtScene* s, const RtRay* rays, uint64_t n, uint64_t seed, RtHit* 
     void *d_rays_v = nullptr, *d_out = nullptr, *d_work_v = nullptr;
     if (int rc = stage_buffer(s, 0, n * sizeof(RtRay), &d_rays_v)) return rc;
     if (int rc = stage_buffer(s, 1, out_bytes, &d_out)) return rc;
-    if (int rc = stage_buffer(s, 2, kWorkWords * sizeof(unsigned long long), &d_work_v)) return rc;
+    if (int rc = stage_buffer(s, 2, kCounterWords * sizeof(unsigned long long), &d_work_v)) return rc;
     RtRay* d_rays = static_cast<RtRay*>(d_rays_v);
     unsigned long long* d_work = work ? static_cast<unsigned long long*>(d_work_v) : nullptr;
     for (hipEvent_t& e : s->ev_trace)
         if (!e) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipMemcpy(d_rays, rays, n * sizeof(RtRay), hipMemcpyHostToDevice));
-    if (work) HIP_TRY(hipMemset(d_work, 0, kWorkWords * sizeof(unsigned long long)));
+    if (work) HIP_TRY(hipMemset(d_work, 0, kCounterWords * sizeof(unsigned long long)));
     if (int rc = ensure_workspace(s, 0)) return rc;
     uint32_t* cursor = s->ws.counts + 3;
     HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t), nullptr));
@@ -799,7 +805,7 @@ int rt_path_step(RtScene* s, const RtRenderParams* p, int profile, const RtRay* 
     hipStream_t stream = nullptr;
     HIP_TRY(hipMemcpy(d_rays_v, rays, n * sizeof(RtRay), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_idx, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemsetAsync(w.ray_total, 0, (1 + kRenderWorkWords) * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(w.ray_total, 0, (1 + kCounterWords) * sizeof(unsigned long long), stream));
 
     RenderConst C{};
     C.seed = p->seed;

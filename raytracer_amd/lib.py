@@ -253,11 +253,12 @@ class DeviceScene:
     def render_work(self, cam, params, accum_ptr, stream=None):
         """rt_render_work: returns (stats, work dict) for an instrumented render into a device buffer."""
         st = abi.RtRenderStats()
-        work = (C.c_uint64 * 12)()
+        work = (C.c_uint64 * 14)()
         self.lib.check(self.lib.lib.rt_render_work(self.h, C.byref(cam), C.byref(params), C.c_void_p(accum_ptr),
                                                   C.c_void_p(stream or 0), C.byref(st), work))
         w = list(work)
-        return st, {"entries": w[0], **{abi.NODE_KINDS[k]: w[1 + k] for k in range(9)}, "lit_slots": w[10]}
+        return st, {"entries": w[0], **{abi.NODE_KINDS[k]: w[1 + k] for k in range(9)}, "lit_slots": w[10],
+                    "first_media": w[11], "first_spheres": w[12]}
 
 
 def kernel_source_hash():
