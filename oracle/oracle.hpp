@@ -468,12 +468,12 @@ struct CullBox {
         self.motion_hull(lo, hi);
         has = (primitive || (!self.unwrap().one_entry() && !(lo <= hi) && self.holds_content())) && self.bounding_box(t0, t1, b);
         if (!has) return;
-        // padded (2^-20 of the box's size and position) before it is rounded outward, so that no face of the object
+        // padded (2^-30 of the box's size and position) before it is rounded outward, so that no face of the object
         // coincides with a face of the box: a hit on such a face at exactly the running closest t would otherwise be
         // culled, where the reference accepts it
         for (int a = 0; a < 3; ++a) {
             const double scale = std::fmax(std::fmax(std::fabs(b._min[a]), std::fabs(b._max[a])), b._max[a] - b._min[a]);
-            const double pad = std::fmax(scale, 1e-30) * (1.0 / 1048576.0);
+            const double pad = std::fmax(scale, 1e-30) * 0x1p-30;
             fbox.lo[a] = f32_down(b._min[a] - pad);
             fbox.hi[a] = f32_up(b._max[a] + pad);
         }
@@ -1039,7 +1039,7 @@ struct BVHNode : Hittable {  // :10-15
         if (!has_cover) return;
         for (int a = 0; a < 3; ++a) {  // padded like CullBox
             const double scale = std::fmax(std::fmax(std::fabs(all._min[a]), std::fabs(all._max[a])), all._max[a] - all._min[a]);
-            const double pad = std::fmax(scale, 1e-30) * (1.0 / 1048576.0);
+            const double pad = std::fmax(scale, 1e-30) * 0x1p-30;
             cover.lo[a] = f32_down(all._min[a] - pad);
             cover.hi[a] = f32_up(all._max[a] + pad);
         }

@@ -369,7 +369,7 @@ inline bool cull_boxes_enabled() {
 }
 inline double cull_pad(double mn, double mx) {
     const double scale = std::fmax(std::fmax(std::fabs(mn), std::fabs(mx)), mx - mn);
-    return std::fmax(scale, 1e-30) * (1.0 / 1048576.0);
+    return std::fmax(scale, 1e-30) * 0x1p-30;
 }
 struct CullBox {
     mutable AABB box;
@@ -390,8 +390,12 @@ struct CullBox {
         const uint32_t at = f.push_node(RT_N_INNER, 0);
         // Padded before it is rounded outward: no face of the object may coincide with a face of this box, or a hit
         // on that face at exactly the running closest t (two objects hit at the same t, where the reference lets the
-        // later one win) would be culled by the test's `far <= near`. The pad is relative to the box (2^-20 of its
-        // size and position), far above rounding noise and far below anything a picture shows.
+        // later one win) would be culled by the test's `far <= near`. The pad is relative to the box (2^-30 of its
+        // size and position): a million times the rounding noise of the f64 box test, and below one unit in the last
+        // place of the f32 planes, so that the box stays as tight as f32 allows. Tight matters: a ray that leaves a face
+        // of a box of six sides starts inside that box's padded culling box, and is only spared the box's six plane tests
+        // if it is out of the padding before tmin = 0.0001 (with 2^-20 it never was: every such ray tested the box it
+        // had just left).
         for (int a = 0; a < 3; ++a) {
             const double pad = cull_pad(box._min[a], box._max[a]);
             f.nodes[at].lo[a] = f32_down(box._min[a] - pad);

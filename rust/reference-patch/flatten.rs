@@ -162,8 +162,8 @@ pub fn flatten_triangle(t: &Triangle, f: &mut Flat) {                       // s
         p0: a3(&t.point0), e1: a3(&(t.point1 - t.point0)), e2: a3(&(t.point2 - t.point0)), mat: t.mp.describe(f), prim_id: f.prim_id() });
 }
 pub fn flatten_list(l: &HittableList, f: &mut Flat) { for o in &l.objects { o.flatten(f); } }   // visit order of :151-164
-/// 2^-20 of a box's size and position: no face of the content may coincide with a face of a box put in front of it.
-fn cull_pad(mn: f64, mx: f64) -> f64 { mn.abs().max(mx.abs()).max(mx - mn).max(1e-30) / 1048576.0 }
+/// 2^-30 of a box's size and position: no face of the content may coincide with a face of a box put in front of it.
+fn cull_pad(mn: f64, mx: f64) -> f64 { mn.abs().max(mx.abs()).max(mx - mn).max(1e-30) / 1073741824.0 }
 /// `full_bounds`: one more method to add to `trait Hittable` (default `None`): the box that holds the object over the
 /// whole motion of every MovingSphere inside it (`bounding_box(time0, time1)` of each sphere's own interval, the plain
 /// `bounding_box` of everything static, the union for lists and BVHNodes; `None` behind a Translate / RotateY). A node
