@@ -535,11 +535,20 @@ RT_D void add_radiance(const PathState& P, uint32_t slot, V3 add) {
 // What shading a hit involves, as a sort key: 0 = miss, else 1 + material kind * 32 + texture kind * 8 + primitive
 // kind. The last bin is reserved for "no ray".
 constexpr uint32_t SORT_BINS = 192u;                      // 3 per lane of the wave that scans them
+// Records per thread and sorting window of the sorting shade kernel: two sizes are built. Measured on the final scene
+// (seven kinds of shading), shade ms per 1024-spp step by records per thread: 2 -> 271, 4 -> 201, 8 -> 175, 12 -> 168,
+// 16 -> 168 before the kernel also asked the media of the next ray; with that work in: 8 -> 210, 12 -> 200, 18 -> 195,
+// 20 -> 192.5, 24 -> 192.8, 28 -> 191.5. Cornell smoke (three kinds): 12 -> 138, 18 -> 140, 20 -> 141, 24 -> 148. The host
+// picks the larger window for scenes with many kinds.
 #ifndef RT_SORT_ROUNDS
-#define RT_SORT_ROUNDS 12  // measured on the final scene, shade ms per 1024-spp step: 2 -> 271, 4 -> 201, 8 -> 175, 12 -> 168, 16 -> 168, 24 -> 167
+#define RT_SORT_ROUNDS 12
 #endif
-constexpr uint32_t SORT_ROUNDS = RT_SORT_ROUNDS;                      // records per thread and window
-constexpr uint32_t SORT_WINDOW = SHADE_BLOCK * SORT_ROUNDS;
+#ifndef RT_SORT_ROUNDS_WIDE
+#define RT_SORT_ROUNDS_WIDE 20
+#endif
+constexpr uint32_t SORT_ROUNDS = RT_SORT_ROUNDS, SORT_ROUNDS_WIDE = RT_SORT_ROUNDS_WIDE;
+constexpr uint32_t sort_window(uint32_t rounds) { return SHADE_BLOCK * rounds; }
+static_assert(sort_window(SORT_ROUNDS_WIDE) <= 65536u, "positions within a window are kept in 16 bits");
 template <class SC>
 RT_D uint32_t shade_key(const SC& S, uint32_t ref) {
     if (ref == RT_MISS) return 0u;
@@ -628,7 +637,7 @@ struct SurvivorOut {
     }
 };
 
-template <bool SORT, class SC>
+template <uint32_t ROUNDS, class SC>  // ROUNDS: records per thread of a sorting window, 0 = no sorting
 RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
                     unsigned long long* __restrict__ ray_total) {
     const uint32_t n = bounce == 0u ? C.n_slots : counts[cur];
@@ -646,7 +655,8 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
     out.next_count = counts + (cur ^ 1u);
     out.chunk = n / total_waves >= OUT_MIN_CHUNKS * OUT_CHUNK ? OUT_CHUNK : 0u;
     out.o_next = 0u; out.o_end = 0u; out.survivors = 0u;
-  if constexpr (SORT) {
+  constexpr uint32_t SORT_WINDOW = sort_window(ROUNDS);
+  if constexpr (ROUNDS != 0u) {
     // Scenes with many kinds of material: every workgroup walks windows of SORT_WINDOW records. The rays of a window are sorted by what shading them
     // involves (counting sort in LDS) and handed out 64 at a time to whichever wave is free, so that a wave mostly
     // runs one branch of shade_one instead of all of them.
@@ -660,9 +670,9 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
     for (uint32_t base = blockIdx.x * SORT_WINDOW; base < n; base += gridDim.x * SORT_WINDOW, ++round) {
         uint32_t* hist = s_hist[round & 1u];
         uint16_t* perm = s_perm[round & 1u];
-        uint32_t keys[SORT_ROUNDS], ranks[SORT_ROUNDS];
+        uint32_t keys[ROUNDS], ranks[ROUNDS];
 #pragma unroll
-        for (uint32_t k = 0; k < SORT_ROUNDS; ++k) {
+        for (uint32_t k = 0; k < ROUNDS; ++k) {
             const uint32_t i = base + k * SHADE_BLOCK + threadIdx.x;
             uint32_t key = SORT_BINS - 1u;  // no ray: beyond n, or a padding record
             if (i < n) {
@@ -685,7 +695,7 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
         }
         __syncthreads();
 #pragma unroll
-        for (uint32_t k = 0; k < SORT_ROUNDS; ++k) perm[hist[keys[k]] + ranks[k]] = (uint16_t)(k * SHADE_BLOCK + threadIdx.x);
+        for (uint32_t k = 0; k < ROUNDS; ++k) perm[hist[keys[k]] + ranks[k]] = (uint16_t)(k * SHADE_BLOCK + threadIdx.x);
         // the other set of bins and the other chunk counter are free again: every wave is past their last use
         if (threadIdx.x < SORT_BINS) s_hist[(round & 1u) ^ 1u][threadIdx.x] = 0u;
         if (threadIdx.x == 0u) s_next_chunk[(round & 1u) ^ 1u] = 0u;
@@ -770,22 +780,22 @@ RT_D void shade_all(const SC& S, const RenderConst& C, const PathState& P, uint3
 }
 
 // LDS bytes the sorting variant of the shade kernel declares for itself (bins, permutations, chunk counters)
-constexpr uint32_t SHADE_SORT_LDS = 2u * SORT_BINS * 4u + 2u * SORT_WINDOW * 2u + 16u;
+constexpr uint32_t shade_sort_lds(uint32_t rounds) { return rounds ? 2u * SORT_BINS * 4u + 2u * sort_window(rounds) * 2u + 16u : 0u; }
 // LDS bytes both variants declare for laying out the survivors' records
 constexpr uint32_t SHADE_STAGE_LDS = (SHADE_BLOCK / 64u) * 64u * 6u * 16u;
 
-template <bool LDS, bool SORT>
+template <bool LDS, uint32_t ROUNDS>
 __global__ void __launch_bounds__(SHADE_BLOCK, RT_SHADE_WAVES) k_shade(DevScene S0, LdsPlan plan, RenderConst C, PathState P,
                                                                        uint32_t* __restrict__ counts, uint32_t cur, uint32_t bounce,
                                                                        unsigned long long* __restrict__ ray_total) {
     if constexpr (LDS) {
         const SceneT<true> S = stage_scene(S0, plan);
-        shade_all<SORT>(S, C, P, counts, cur, bounce, ray_total);
+        shade_all<ROUNDS>(S, C, P, counts, cur, bounce, ray_total);
     } else if (plan_is_empty(plan)) {
-        shade_all<SORT>(S0, C, P, counts, cur, bounce, ray_total);
+        shade_all<ROUNDS>(S0, C, P, counts, cur, bounce, ray_total);
     } else {
         const DevScene S = stage_scene_partial(S0, plan);
-        shade_all<SORT>(S, C, P, counts, cur, bounce, ray_total);
+        shade_all<ROUNDS>(S, C, P, counts, cur, bounce, ray_total);
     }
 }
 

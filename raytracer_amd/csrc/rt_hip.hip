@@ -58,7 +58,7 @@ struct RtScene {
     uint32_t lds_bytes_shade = 0;
     uint32_t grid_shade = 256;
     bool extend_lds = false, shade_lds = false;  // which variant of each kernel this scene runs
-    bool shade_sort = false;
+    uint32_t shade_rounds = 0;  // records per thread of the sorting shade kernel's window; 0: the plain kernel
     bool box_media = false;   // some box of six sides sits alone inside wrappers (on its own or as a medium's boundary)
     bool general_media = false;  // some medium's boundary is neither one sphere nor one box alone inside wrappers
     bool boxed_media = false;    // some medium's boundary is one box alone inside zero or more wrappers
@@ -314,8 +314,10 @@ void launch_shade(RtScene* s, const RenderConst& C, uint32_t cur, uint32_t bounc
     Workspace& w = s->ws;
     const dim3 sg(std::min(s->grid_shade, (C.n_slots + rtd::SHADE_BLOCK - 1) / rtd::SHADE_BLOCK)), sb(rtd::SHADE_BLOCK);
 #define RT_LAUNCH_SHADE(L, Q) hipLaunchKernelGGL((rtd::k_shade<L, Q>), sg, sb, s->lds_bytes_shade, stream, s->S, s->plan_shade, C, w.P, w.counts, cur, bounce, w.ray_total)
-    if (s->shade_lds) { if (s->shade_sort) RT_LAUNCH_SHADE(true, true); else RT_LAUNCH_SHADE(true, false); }
-    else { if (s->shade_sort) RT_LAUNCH_SHADE(false, true); else RT_LAUNCH_SHADE(false, false); }
+#define RT_LAUNCH_SHADE_L(L) do { if (s->shade_rounds == rtd::SORT_ROUNDS_WIDE) RT_LAUNCH_SHADE(L, rtd::SORT_ROUNDS_WIDE); \
+                                  else if (s->shade_rounds) RT_LAUNCH_SHADE(L, rtd::SORT_ROUNDS); else RT_LAUNCH_SHADE(L, 0u); } while (0)
+    if (s->shade_lds) RT_LAUNCH_SHADE_L(true); else RT_LAUNCH_SHADE_L(false);
+#undef RT_LAUNCH_SHADE_L
 #undef RT_LAUNCH_SHADE
 }
 
@@ -504,11 +506,13 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
 #define RT_SORT_MIN_CLASSES 6
 #endif
                 // a scene with media and three kinds also gains (Cornell smoke: 886 -> 913 M samples/s)
-                s->shade_sort = classes >= RT_SORT_MIN_CLASSES || (d->n_media > 0 && classes >= 3);
+                // with many kinds the larger window pays as well (final scene: shade 200 -> 192.5 ms per step), with few it
+                // costs (Cornell smoke: 138 -> 141)
+                s->shade_rounds = classes >= RT_SORT_MIN_CLASSES ? rtd::SORT_ROUNDS_WIDE : ((d->n_media > 0 && classes >= 3) ? rtd::SORT_ROUNDS : 0u);
             }
             const uint32_t kPlainBudget = kBudget - rtd::SHADE_STAGE_LDS;
-            const uint32_t kSortBudget = kPlainBudget - ((rtd::SHADE_SORT_LDS + 1023u) & ~1023u);
-            const uint32_t kShadeBudget = s->shade_sort ? kSortBudget : kPlainBudget;
+            auto sort_budget = [&](uint32_t rounds) { return kPlainBudget - ((rtd::shade_sort_lds(rounds) + 1023u) & ~1023u); };
+            const uint32_t kShadeBudget = sort_budget(s->shade_rounds);
             auto pad = [](uint64_t bytes) { return (bytes + 15u) & ~15ull; };
             const uint64_t prims = pad(d->n_spheres * sizeof(RtSphere)) + pad(d->n_msphere * sizeof(RtMovingSphere)) + pad(d->n_rects * sizeof(RtRect)) +
                                    pad(d->n_boxes * sizeof(RtBox6)) + pad(d->n_triangles * sizeof(RtTriangle)) + pad(d->n_xforms * sizeof(RtXform)) +
@@ -572,10 +576,10 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
                          RT_BIG_LDS((rtd::k_extend<true, false, PR>)); RT_BIG_LDS((rtd::k_extend<true, true, PR>))
             RT_BIG_LDS_P(0); RT_BIG_LDS_P(1); RT_BIG_LDS_P(3); RT_BIG_LDS_P(4); RT_BIG_LDS_P(5); RT_BIG_LDS_P(7); RT_BIG_LDS_P(8); RT_BIG_LDS_P(12);
 #undef RT_BIG_LDS_P
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlainBudget);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortBudget);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlainBudget);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSortBudget);
+#define RT_SHADE_LDS(L, Q) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtd::k_shade<L, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_budget(Q))
+            RT_SHADE_LDS(false, 0u); RT_SHADE_LDS(false, rtd::SORT_ROUNDS); RT_SHADE_LDS(false, rtd::SORT_ROUNDS_WIDE);
+            RT_SHADE_LDS(true, 0u); RT_SHADE_LDS(true, rtd::SORT_ROUNDS); RT_SHADE_LDS(true, rtd::SORT_ROUNDS_WIDE);
+#undef RT_SHADE_LDS
 #define RT_BIG_LDS_T(W, L) RT_BIG_LDS((rtd::k_trace<W, L, false>)); RT_BIG_LDS((rtd::k_trace<W, L, true>))
             RT_BIG_LDS_T(false, false); RT_BIG_LDS_T(false, true); RT_BIG_LDS_T(true, false); RT_BIG_LDS_T(true, true);
 #undef RT_BIG_LDS_T
@@ -602,12 +606,12 @@ int rt_scene_create(const RtSceneDesc* d, RtScene** out) {
         s->grid_extend = s->n_cus * (uint32_t)per_cu;
         if (const char* e = std::getenv("RT_EXTEND_CUS")) s->grid_extend = (uint32_t)std::max(1, std::atoi(e)) * (uint32_t)per_cu;  // developer knob
         int shade_per_cu = 0;
-        if (s->shade_sort)
-            oe = s->shade_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, rtd::k_shade<true, true>, rtd::SHADE_BLOCK, s->lds_bytes_shade)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, rtd::k_shade<false, true>, rtd::SHADE_BLOCK, s->lds_bytes_shade);
-        else
-            oe = s->shade_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, rtd::k_shade<true, false>, rtd::SHADE_BLOCK, s->lds_bytes_shade)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, rtd::k_shade<false, false>, rtd::SHADE_BLOCK, s->lds_bytes_shade);
+#define RT_SHADE_OCC(L, Q) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, rtd::k_shade<L, Q>, rtd::SHADE_BLOCK, s->lds_bytes_shade)
+#define RT_SHADE_OCC_L(L) do { if (s->shade_rounds == rtd::SORT_ROUNDS_WIDE) RT_SHADE_OCC(L, rtd::SORT_ROUNDS_WIDE); \
+                               else if (s->shade_rounds) RT_SHADE_OCC(L, rtd::SORT_ROUNDS); else RT_SHADE_OCC(L, 0u); } while (0)
+        if (s->shade_lds) RT_SHADE_OCC_L(true); else RT_SHADE_OCC_L(false);
+#undef RT_SHADE_OCC_L
+#undef RT_SHADE_OCC
         if (oe != hipSuccess || shade_per_cu < 1) shade_per_cu = 1;
 #ifndef RT_SHADE_GRID_MULT
 #define RT_SHADE_GRID_MULT 1
