@@ -10,7 +10,7 @@ RAYS_PER_LAUNCH: give it for a scene whose tables live in HBM. FETCH_SIZE tallie
 records at half their bytes and scattered 32-byte entry reads at the 64 bytes they fetch (tools/fetch_calibrate.hip), so
 for a scene in LDS (reads = records only) FETCH_SIZE is doubled, and for a scene in HBM only the records' missing half,
 48 bytes per ray, is added.
-Environment: SHADE_KERNEL (e.g. "rtd::k_shade<true, true>") and SHADE_SECONDS_PER_STEP also record the shade launches of
+Environment: SHADE_KERNEL (e.g. "rtd::k_shade<true, 20u>") and SHADE_SECONDS_PER_STEP also record the shade launches of
 one step under KEY + "/shade": the sorting variant gathers whole records through a permutation, which FETCH_SIZE tallies
 at 0.89 of the bytes (tools/fetch_calibrate.hip), the plain variant streams them in order (tallied at half).
 Every record carries a hash of the kernel sources it was measured with; bench.py ignores records of other sources."""
@@ -67,7 +67,7 @@ def main(key, tag, kernel, spp, secs, rays_per_launch=None):
         sf = counters(os.path.join(prof, tag + "_pmc_fetch.txt"), shade)
         sw = counters(os.path.join(prof, tag + "_pmc_write.txt"), shade)
         steps = sf["_dispatches"] / 50.0  # 50 launches per step (the timed step and the instrumented pass of bench.py)
-        sorting = shade.rstrip(">").split(",")[-1].strip() == "true"
+        sorting = shade.rstrip(">").split(",")[-1].strip() not in ("0u", "0", "false")  # k_shade<LDS, records per thread of the sorting window>
         factor = 1.0 / 0.89 if sorting else 2.0
         t[key + "/shade"] = {"kernel": shade, "launches": sf["_dispatches"], "fetch_size_kib": sf["FETCH_SIZE"], "write_size_kib": sw["WRITE_SIZE"],
                              "bytes_per_step": (factor * sf["FETCH_SIZE"] + sw["WRITE_SIZE"]) * 1024.0 / steps,
