@@ -210,6 +210,33 @@ def test_media_asked_before_the_walk(gpu, orc, monkeypatch):
     orc.api.scene_free(oroot)
 
 
+def test_a_world_of_nothing_but_media_asked_first(gpu, orc):
+    # the library's copy of the entry stream is empty: both media are asked before a walk that has nothing to visit
+    roots = []
+    for api in (gpu.host, orc.api):
+        b = api.builder(seed=3)
+        lam = b.lambertian([0.5, 0.5, 0.5])
+        objs = [b.constant_medium(b.sphere([0.0, 0.0, 0.0], 3.0, lam), 0.3, [1.0, 1.0, 1.0]),
+                b.constant_medium(b.sphere([1.0, 0.5, 0.0], 1.5, lam), 0.9, [0.2, 0.4, 0.9])]
+        roots.append(b.finish(b.bvh(b.list(objs), 0.0, 1.0)))
+    hroot, oroot = roots
+    hs = lib.HostScene(gpu, hroot)
+    ds = lib.DeviceScene(hs)
+    rays = random_rays(np.random.default_rng(5), 5000)
+    oh, _, ost = orc.trace(oroot, rays, seed=9, mode=oracle_mode(hs))
+    gh, work = ds.trace_work(rays, seed=9)
+    compare_hits(oh, gh, "media only")
+    assert (oh["prim_id"] != abi.RT_MISS).sum() > 500
+    assert work["inner"] == ost["box_tests"] == 0 and work["medium"] == ost["medium"] == 2 * len(rays) and work["sphere"] == ost["sphere"]
+    ref, _, _ = orc.trace(oroot, rays, seed=9, mode=oracle.AABB_REFERENCE)
+    assert np.array_equal(ref["prim_id"], oh["prim_id"]) and np.array_equal(ref["t"].view(np.uint64), oh["t"].view(np.uint64))
+    su = gpu.host.scene_setup(9)
+    cam = gpu.host.camera(su)
+    acc, st = ds.render(cam, lib.make_params(32, 32, 0, 2, [0.1, 0.2, 0.3]))  # and a render over it does not trip either
+    assert np.isfinite(acc).all() and st.rays >= 32 * 32 * 2
+    ds.close(); hs.close(); orc.api.scene_free(oroot)
+
+
 def test_boxes_that_do_not_bound_their_spheres(gpu, orc):
     # A tree built over t in (0, 0.2) around spheres that move over (0, 1), as the reference's random_scene does
     # (src/main.rs:315): the closest hit then depends on the box rule. The flattener flags such a scene and the
