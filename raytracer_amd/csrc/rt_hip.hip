@@ -163,9 +163,10 @@ int validate(const RtSceneDesc* d) {
 // Media that are asked before the walk instead of inside it (rtd::deferred_media, rtd::first_candidate): RT_N_MEDIUM
 // entries in world space (inside no wrapper) whose boundary is one sphere, the first rtd::MAX_DEFERRED_MEDIA of them in
 // stream order (box-bounded media such as cornell_smoke's were tried too: their twelve divisions per medium cost the
-// shade launch as much as the walk saves). What a medium answers does not depend on when it is asked (its random number is keyed by the medium),
-// and a walk spends a whole round of a thinly filled wave on such an entry (measured on final_scene: 11 % of the lanes
-// for the medium inside the glass sphere), while the kernels that make rays ask with full waves. They leave the
+// shade launch as much as the walk saves). What a medium answers does not depend on when it is asked (its random
+// number is keyed by the medium), and a walk spends a whole round of a thinly filled wave on such an entry (measured on
+// final_scene: 11 % of the lanes for the medium inside the glass sphere), while the kernels that make rays ask with full
+// waves. They leave the
 // library's copy of the stream (`out` = the stream without them, links moved), and box entries that are left with
 // nothing below go with them. In a scene whose boxes may not bound their contents only media that every ray reaches
 // (under no box entry) are taken: its covering boxes come in pairs that must stay whole.
