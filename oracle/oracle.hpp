@@ -669,8 +669,13 @@ struct RotateY : Hittable {  // :306-392
     uint32_t id;
     RotateY(HitPtr p, double angle) : ptr(std::move(p)), id(take_inst_id()) {  // :315-350
         double radians = degrees_to_radians(angle);
+        // Two libm calls, as the reference writes them (radians.sin(), radians.cos(), :317-319). Left alone GCC merges
+        // them into one sincos() call, and glibc's sincos differs from its sin / cos in the last bit for about one angle
+        // in a thousand: enough to move a grazing hit inside the wrapper by hundreds of units in the last place. The
+        // product's host library (built by clang) makes the two calls.
         sin_theta = std::sin(radians);
-        cos_theta = std::cos(radians);
+        volatile double radians_again = radians;
+        cos_theta = std::cos(radians_again);
         Point min(INF, INF, INF);
         Point max(-INF, -INF, -INF);
         hasbox = ptr->bounding_box(0.0, 1.0, bbox);

@@ -156,9 +156,9 @@ class HostScene:
                   "textures": "n_textures", "perlins": "n_perlins", "images": "n_images"}
         n = getattr(self.desc, counts[name])
         ptr = getattr(self.desc, name)
-        if n == 0:
-            return []
         typ = ptr._type_
+        if n == 0:
+            return np.zeros(0, dtype=np.dtype(typ))
         arr = (typ * n).from_address(C.addressof(ptr.contents))
         return np.frombuffer(bytes(arr), dtype=np.dtype(typ))
 

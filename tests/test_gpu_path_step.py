@@ -22,6 +22,9 @@ from raytracer_amd import abi, lib
 
 pytestmark = pytest.mark.gpu
 
+# seeded random scenes per test; RT_FUZZ_CASES widens the campaign for a one-off run (e.g. 100)
+FUZZ_CASES = int(os.environ.get("RT_FUZZ_CASES", "12"))
+
 T_ULP = 4
 PROFILES = (0, 1, 3, 4, 5, 7)
 M_LAMBERTIAN, M_METAL, M_DIELECTRIC, M_LIGHT, M_ISOTROPIC = range(5)
@@ -75,6 +78,8 @@ def material_kinds(hs, hits):
     m = mat_of[np.where(hit, hits["prim_id"], 0)]
     mk = np.where(hit, mats["kind"][m], -1)
     textured = np.isin(mk, (M_LAMBERTIAN, M_LIGHT, M_ISOTROPIC))
+    if len(texs) == 0:  # a scene whose objects all took the materials without a texture
+        return mk, np.full(len(mk), -1)
     tk = np.where(textured, texs["kind"][np.where(textured, mats["tex"][m], 0)], -1)
     return mk, tk
 
@@ -175,7 +180,7 @@ def test_seeded_rays_through_the_render_kernels(gpu, orc, sid, extra):
     ds.close(); hs.close(); orc.api.scene_free(osc)
 
 
-@pytest.mark.parametrize("case", range(6))
+@pytest.mark.parametrize("case", range(FUZZ_CASES))
 def test_random_scenes_through_the_render_kernels(gpu, orc, case):
     from test_gpu_trace import random_rays, random_scene_pair
     rng = np.random.default_rng(4321 + case)
@@ -193,7 +198,7 @@ def test_random_scenes_through_the_render_kernels(gpu, orc, case):
     oh, _, ost = orc.trace(oroot, rays, seed=77, mode=oracle_mode(hs))
     want = orc.path_step(oroot, p, rays, mode=oracle_mode(hs))
     mk, tk = material_kinds(hs, oh)
-    assert (want["prim_id"] != abi.RT_MISS).sum() > 100
+    assert (want["prim_id"] != abi.RT_MISS).sum() > 40
     for pr in legal_profiles(hs):
         got, work = ds.path_step(p, rays, profile=pr, want_work=True)
         compare_steps(want, got, mk, tk, "random scene %d profile %d" % (case, pr), media=True)

