@@ -124,11 +124,20 @@ int validate(const RtSceneDesc* d) {
     }
     // entry stream: links forward and inside the stream, indices inside their tables, wrappers balanced
     const uint64_t table_n[9] = {0, d->n_spheres, d->n_msphere, d->n_rects, d->n_boxes, d->n_triangles, d->n_xforms, d->n_xforms, d->n_media};
+    // Ranges nest, among themselves and with the wrappers: the walk skips from a box or medium entry to its link and
+    // must arrive in the space it left, and a boundary walk must end in the space of its medium. (A stream that breaks
+    // this is walked without a fault, but with the wrong ray.)
+    struct Range { uint64_t end; size_t depth; };
     std::vector<uint32_t> open;        // xform stack
+    std::vector<Range> ranges;         // box / medium entries we are inside, innermost last, and the wrapper depth they began at
     uint64_t medium_end = 0;           // end of the boundary range we are inside (0 = none)
     for (uint64_t i = 0; i < d->n_nodes; ++i) {
         const RtNode& n = d->nodes[i];
         const uint32_t kind = n.meta & 15u, idx = n.meta >> 4;
+        while (!ranges.empty() && ranges.back().end == i) {
+            if (open.size() != ranges.back().depth) return bad("the range of a box or medium entry ends inside a wrapper entered within it");
+            ranges.pop_back();
+        }
         if (kind > RT_N_MEDIUM) return bad("entry kind");
         if (kind != RT_N_INNER && idx >= table_n[kind]) return bad("entry -> table index");
         if (kind == RT_N_INNER && idx > RT_INNER_COVER) return bad("box entry with an unknown marker");
@@ -140,6 +149,8 @@ int validate(const RtSceneDesc* d) {
         if (kind == RT_N_INNER || kind == RT_N_MEDIUM) {
             if (n.link <= i || n.link > d->n_nodes) return bad("entry link");
             if (medium_end && n.link > medium_end) return bad("entry link leaves the medium boundary");
+            if (!ranges.empty() && n.link > ranges.back().end) return bad("entry link leaves the range of the entry around it");
+            ranges.push_back({n.link, open.size()});
         }
         if (kind == RT_N_MEDIUM) {
             if (medium_end) return bad("medium inside a medium boundary");
@@ -153,10 +164,13 @@ int validate(const RtSceneDesc* d) {
             open.push_back(idx);
         } else if (kind == RT_N_XF_EXIT) {
             if (open.empty() || open.back() != idx) return bad("unbalanced wrapper exit");
+            if (!ranges.empty() && open.size() - 1u < ranges.back().depth) return bad("wrapper left inside the range of an entry that began within it");
             open.pop_back();
         }
     }
     if (!open.empty()) return bad("unbalanced wrapper enter");
+    for (const Range& r : ranges)
+        if (r.depth != 0u) return bad("the range of a box or medium entry ends inside a wrapper entered within it");
     return RT_OK;
 }
 
