@@ -70,7 +70,12 @@ enum RtError {
  *   RT_N_XF_EXIT : index of the wrapper being left
  *   RT_N_MEDIUM  : index into media; entries [i+1, link) are the boundary
  *                  object (src/constant_medium.rs:11), queried twice
- * lo/hi are unused (0) except for RT_N_INNER. */
+ * lo/hi are unused (0) except for RT_N_INNER.
+ * The ranges [i, link) of RT_N_INNER and RT_N_MEDIUM entries nest, with each other
+ * and with the wrappers: a wrapper entered inside a range is left inside it, and a
+ * range begun inside a wrapper ends before the wrapper is left (a depth-first
+ * linearisation gives this by construction; rt_scene_create refuses a stream that
+ * does not have it). */
 typedef struct RtNode {
     float lo[3];
     float hi[3];
