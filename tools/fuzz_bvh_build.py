@@ -1,5 +1,5 @@
-"""GPU box: seeded campaign of rt_bvh_build against the oracle's CPU statement of the same tree (tokens bit for bit) over
-box sets of random size and shape: clustered, duplicated, flat, identical, tiny and huge coordinates.
+"""GPU box: seeded campaign of rt_bvh_build, rt_bvh_build_device and rt_bvh_build_device_noalloc against the oracle's CPU
+statement of the same tree (tokens bit for bit) over box sets of random size and shape: clustered, duplicated, flat, identical, tiny and huge coordinates.
     python tools/fuzz_bvh_build.py [N_CASES]"""
 import os
 import sys
@@ -8,7 +8,24 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 
 import oracle
-from raytracer_amd import lib
+from raytracer_amd import abi, lib
+
+NOALLOC_MAX = 65536  # RT_BVH_NOALLOC_MAX_OBJECTS
+
+
+def device_build(gpu, entry, boxes):
+    """rt_bvh_build_device / rt_bvh_build_device_noalloc on device-resident boxes (torch holds the memory)."""
+    import torch
+    n = boxes.shape[0]
+    d_boxes = torch.from_numpy(np.ascontiguousarray(boxes, dtype=np.float64)).cuda()
+    d_tokens = torch.zeros((2 * n - 1) * abi.NODE_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    args = [d_boxes.data_ptr(), n, d_tokens.data_ptr(), None, None]
+    if entry == "rt_bvh_build_device":
+        args.append(None)
+    gpu.check(getattr(gpu.lib, entry)(*args))
+    torch.cuda.synchronize()
+    return d_tokens.cpu().numpy().tobytes()
 
 
 def box_set(rng):
@@ -46,9 +63,13 @@ def main(n_cases):
         boxes, style = box_set(rng)
         got, _ = gpu.bvh_build(boxes)
         want = orc.lbvh_tokens(boxes)
-        if got.tobytes() != want.tobytes():
+        same = got.tobytes() == want.tobytes()
+        # the device-resident entry points, the second of them in the shared static scratch array (calls of every size in a row)
+        same_dev = device_build(gpu, "rt_bvh_build_device", boxes) == want.tobytes()
+        same_noalloc = len(boxes) > NOALLOC_MAX or device_build(gpu, "rt_bvh_build_device_noalloc", boxes) == want.tobytes()
+        if not (same and same_dev and same_noalloc):
             bad += 1
-            print("case %d: %d boxes, style %d: tokens differ" % (case, len(boxes), style))
+            print("case %d: %d boxes, style %d: host-buffer build %s, device build %s, no-alloc build %s" % (case, len(boxes), style, same, same_dev, same_noalloc))
     print("%d box sets: %d mismatches" % (n_cases, bad))
     return 1 if bad else 0
 
