@@ -91,6 +91,8 @@ def compare_steps(want, got, mk, tk, what, media):
     d = np.zeros(len(want), dtype=np.int64)
     d[hit] = ulp_diff(want["t"][hit], got["t"][hit])
     assert d.max(initial=0) <= (T_ULP if media else 0), what + ": t off by %d ulp" % d.max(initial=0)
+    # only a medium's t goes through log10 (device math library against the C library): everything else to the bit
+    assert d[mk != M_ISOTROPIC].max(initial=0) == 0, what + ": t of a hit that is no medium's off by %d ulp" % d[mk != M_ISOTROPIC].max(initial=0)
     assert np.array_equal(want["scattered"], got["scattered"]), what + ": scatter decisions differ"
     assert np.array_equal(want["emitted"], got["emitted"]), what + ": emitted light differs"
     sc = want["scattered"] == 1

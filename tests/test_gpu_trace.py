@@ -21,12 +21,17 @@ FUZZ_CASES = int(os.environ.get("RT_FUZZ_CASES", "12"))
 T_ULP = 4  # north-star tolerance on t
 
 
-def compare_hits(oh, gh, what=""):
+def compare_hits(oh, gh, what="", media_ids=None):
+    """media_ids: the prim ids of the scene's media; given them, t must agree to the bit on everything else (only a
+    medium's t goes through log10, which the device's math library and the C library round differently)."""
     assert np.array_equal(oh["prim_id"], gh["prim_id"]), what + ": primitive ids differ"
     assert np.array_equal(oh["sub"], gh["sub"]), what + ": box side / wrapper ids differ"
     hit = oh["prim_id"] != abi.RT_MISS
     d = ulp_diff(oh["t"][hit], gh["t"][hit])
     assert d.max(initial=0) <= T_ULP, what + ": t off by %d ulp" % d.max(initial=0)
+    if media_ids is not None:
+        solid = ~np.isin(oh["prim_id"][hit], np.asarray(list(media_ids), dtype=np.uint32))
+        assert d[solid].max(initial=0) == 0, what + ": t of a hit that is no medium's off by %d ulp" % d[solid].max(initial=0)
     # u, v go through atan2/asin on spheres (libm vs device math): a few ulp of values in [0, 1]
     # (a NaN on both sides is agreement: a ray lying in the plane of a rect has t = 0 / 0, which the reference's range
     # and bounds checks let through, src/aarect.rs:31-39)
@@ -158,7 +163,8 @@ def test_random_scenes_all_primitive_kinds(gpu, orc, case):
     rays = random_rays(rng, 20000)
     oh, orec, _ = orc.trace(oroot, rays, seed=77, mode=oracle_mode(hs), records=True)
     gh, _ = ds.trace(rays, seed=77)
-    compare_hits(oh, gh, "random scene %d" % case)
+    media = hs.table("media")
+    compare_hits(oh, gh, "random scene %d" % case, media_ids=media["prim_id"] if len(media) else [])
     grec = ds.trace_records(rays, seed=77)
     hit = oh["prim_id"] != abi.RT_MISS
     assert hit.sum() > 40
